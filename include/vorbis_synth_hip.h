@@ -1,0 +1,186 @@
+/*
+ * vorbis_synth_hip.h — C-ABI of the MI355X-native batched Vorbis spectral-synthesis path.
+ *
+ * This is the drop-in boundary for ONE hot path of albertz/ParseOggVorbis: everything the reference
+ * does per audio packet AFTER the entropy decode, i.e.
+ *
+ *   floor-1 amplitude unwrap + curve render   src/ParseOggVorbis.hpp:521-590, src/Utils.hpp:58-183
+ *   nonzero-vector propagate                  src/ParseOggVorbis.hpp:1174-1180
+ *   inverse channel coupling                  src/ParseOggVorbis.hpp:1213-1241
+ *   floor x residue ("dot product")           src/ParseOggVorbis.hpp:1243-1255
+ *   inverse MDCT                              src/mdct.cpp:433-527 (tables: src/mdct.cpp:88-127)
+ *   window + overlap-add + PCM hand-off       src/ParseOggVorbis.hpp:837-886, 1008-1109
+ *
+ * The reference runs that per packet inside VorbisStream::parse_audio (hpp:1128-1274); a host decoder
+ * that keeps the sequential Ogg/Huffman parse on the CPU calls vsyn_submit_* once per BATCH instead
+ * (between hpp:1211 "after_residue" and hpp:1213), then replays hooks / ParseCallbacks::gotPcmData in
+ * packet order.  Plain C: POD structs, raw pointers and sizes, int status + const char** error, no
+ * C++/torch types, no exceptions across the boundary.  All compute is HIP on gfx950; there is no CPU
+ * fallback — every entry point fails with VSYN_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef VORBIS_SYNTH_HIP_H_
+#define VORBIS_SYNTH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSYN_ABI_VERSION 1
+
+#define VSYN_MAX_CHANNELS 32 /* floor_used is a 32-bit mask (reference: uint8_t audio_channels) */
+#define VSYN_MAX_POSTS 65    /* Vorbis I: 2 + 31 partitions x <=8 dims, capped at 65 by the spec */
+#define VSYN_MIN_BLOCKSIZE 64
+#define VSYN_MAX_BLOCKSIZE 8192 /* hpp:1294-1296 */
+
+/* status codes (return value of every int function; 0 = ok, like ogg_vorbis_full_read, ParseOggVorbis.cpp:12-42) */
+enum {
+  VSYN_OK = 0,
+  VSYN_ERR_INVALID = 1,   /* bad argument / bad setup (the reference's CHECK(...) on setup fields) */
+  VSYN_ERR_NO_DEVICE = 2, /* no HIP device, or not gfx950-compatible code object */
+  VSYN_ERR_HIP = 3,       /* a HIP runtime call failed; text in *err */
+  VSYN_ERR_STREAM = 4     /* the batch itself is bad (see vsyn_status.flags) */
+};
+
+/* vsyn_status.flags — conditions on which the reference fails a CHECK and aborts the read */
+enum {
+  VSYN_ST_FLOOR_RANGE = 1u << 0,   /* predicted > range, hpp:536 */
+  VSYN_ST_FLOOR_VALUE = 1u << 1,   /* rendered floor value >= 256, hpp:587 */
+  VSYN_ST_GRANULE = 1u << 2,       /* page granule behind/ahead of what the packets provide, hpp:1029,1041 */
+  VSYN_ST_PLANE_OVERFLOW = 1u << 3,/* a segment emits more than plane_stride samples (nothing is written out of bounds) */
+  VSYN_ST_BAD_MODE = 1u << 4       /* mode index >= num_modes */
+};
+
+/* ---- stream setup: the part of VorbisStreamSetup (hpp:889-964) the synthesis half reads ---- */
+
+typedef struct vsyn_floor1 {          /* VorbisFloor1, hpp:416-471 */
+  uint32_t multiplier;                /* 1..4 (hpp:446) */
+  uint32_t num_posts;                 /* xs.size(), 2..65 */
+  const uint32_t* xs;                 /* header order: xs[0]=0, xs[1]=1<<rangebits, then partition posts (hpp:448-456) */
+} vsyn_floor1;
+
+typedef struct vsyn_coupling {        /* VorbisMapping::Coupling, hpp:767 */
+  uint16_t magnitude, angle;
+} vsyn_coupling;
+
+typedef struct vsyn_mapping {         /* VorbisMapping, hpp:765-814 */
+  uint32_t num_couplings;
+  const vsyn_coupling* couplings;     /* in header order; applied in reverse (hpp:1214) */
+  const uint8_t* channel_floor;       /* [channels]: submaps[muxs[ch]].floor (hpp:1162-1163) */
+} vsyn_mapping;
+
+typedef struct vsyn_mode {            /* VorbisModeNumber, hpp:816-835 */
+  uint8_t block_flag;                 /* 1 = long window (blocksize1) */
+  uint8_t mapping;
+} vsyn_mode;
+
+typedef struct vsyn_setup {
+  uint32_t channels;                  /* VorbisIdHeader.audio_channels, 1..VSYN_MAX_CHANNELS */
+  uint32_t blocksize0, blocksize1;    /* powers of two, 64..8192, blocksize0 <= blocksize1 (hpp:1294-1298) */
+  uint32_t num_floors;   const vsyn_floor1* floors;   /* all type 1 (type 0 is unimplemented upstream, hpp:402) */
+  uint32_t num_mappings; const vsyn_mapping* mappings;
+  uint32_t num_modes;    const vsyn_mode* modes;
+} vsyn_setup;
+
+/* ---- a batch ---- */
+
+typedef struct vsyn_packet {          /* what hpp:1142-1172 leaves behind for one audio packet; 16 bytes */
+  uint8_t mode;                       /* mode_idx, hpp:1146 */
+  uint8_t prev_long, next_long;       /* prev/next window flags, hpp:1151-1152 (ignored for short blocks) */
+  uint8_t reserved0;
+  uint32_t floor_used;                /* bit c = VorbisFloor1::decode set use_output for channel c (hpp:478-482) */
+  int64_t granule;                    /* setExpectedEndingPos(): page granule if last packet on its page, else -1 (hpp:1456-1459) */
+} vsyn_packet;
+
+#define VSYN_SEG_RESET 1u             /* segment starts a stream: no overlap carry-in, first packet emits nothing (hpp:1021) */
+
+typedef struct vsyn_segment {         /* consecutive packets of one stream inside a batch; 24 bytes */
+  uint32_t stream;                    /* stream slot, < max_streams; carries overlap state between submits */
+  uint32_t first_packet;              /* index into packets[] / ys rows */
+  uint32_t num_packets;
+  uint32_t flags;                     /* VSYN_SEG_* */
+  uint64_t residue_off;               /* float index of this segment's first residue block (multiple of 4) */
+} vsyn_segment;
+
+/*
+ * Batch tensors (host or device resident depending on the entry point):
+ *   packets  [P]                      vsyn_packet
+ *   segments [S]                      vsyn_segment; segments must not overlap, a stream slot at most once per batch
+ *   ys       [P][channels][ys_stride] uint16  coded floor-1 Y values ("floor1 ys", hpp:518); row ignored if !floor_used
+ *   residue  packed float32: packet p of a segment, channel c, bin i at
+ *              seg.residue_off + (sum of channels*n_q/2 over earlier packets q of the segment) + c*n_p/2 + i
+ *            = "after_residue" (hpp:1211), length n_p/2 per channel
+ *   pcm      [S][channels][plane_stride] float32, planar; segment g writes its emitted samples from offset 0
+ *   emit_len [P] uint32 (optional)    samples per channel emitted for packet p = num_frames of forwardReadyPcm (hpp:1019-1059)
+ */
+typedef struct vsyn_taps {            /* optional debug taps = the reference's push_data_* hooks on this path */
+  float* after_envelope;              /* same packing as residue; "after_envelope", hpp:1254 */
+  float* pcm_after_mdct;              /* packed like residue with n_p per channel (2x offsets); "pcm_after_mdct", hpp:1265 */
+  uint16_t* floor_final;              /* [P][channels][ys_stride]: final_y*multiplier | step2_flag<<15 ("floor1 final_ys"/"step2_flag", hpp:560-561) */
+} vsyn_taps;
+
+typedef struct vsyn_status {
+  uint32_t flags;                     /* VSYN_ST_* OR-ed over the batch */
+  uint32_t first_bad_packet;          /* lowest packet index that raised a flag (0xFFFFFFFF if none) */
+} vsyn_status;
+
+typedef struct vsyn_handle vsyn_handle;
+
+/* submit flags */
+#define VSYN_SUBMIT_STAGED 1u         /* force the staged (tap-capable, any-shape) kernels instead of the fused one */
+
+const char* vsyn_version(void);
+int vsyn_abi_version(void);
+
+/* Builds the per-stream constant block (IMDCT twiddles for both blocksizes, the 1+4 window tables of
+ * VorbisModeNumber::precalc hpp:837-862, floor-1 sorted posts + neighbour tables, coupling/mode tables,
+ * inverse-dB table) on `device` and allocates overlap state for max_streams stream slots. */
+int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_handle** out, const char** err);
+void vsyn_destroy(vsyn_handle* h);
+
+uint32_t vsyn_ys_stride(const vsyn_handle* h);           /* uint16 elements per (packet,channel) row of ys */
+uint32_t vsyn_channels(const vsyn_handle* h);
+/* size in bytes of the constant block, and a copy of it (for the one RCCL broadcast of a multi-GPU job) */
+size_t vsyn_const_block_bytes(const vsyn_handle* h);
+
+/* All pointers are DEVICE pointers on the handle's device; asynchronous on hip_stream (a hipStream_t, NULL = default stream).
+ * max_seg_packets >= every segment's num_packets. Errors found on the device are reported by vsyn_sync_status. */
+int vsyn_submit_device(vsyn_handle* h,
+                       uint32_t num_packets, const vsyn_packet* d_packets,
+                       uint32_t num_segments, const vsyn_segment* d_segments, uint32_t max_seg_packets,
+                       const uint16_t* d_ys, const float* d_residue,
+                       float* d_pcm, uint64_t plane_stride,
+                       uint32_t* d_emit_len, const vsyn_taps* d_taps,
+                       uint32_t flags, void* hip_stream, const char** err);
+
+/* Same with HOST pointers: stages to the device, runs, copies pcm / emit_len / taps back, synchronises,
+ * and returns VSYN_ERR_STREAM (status filled) if the device flagged the batch. residue_floats = total floats in residue. */
+int vsyn_submit_host(vsyn_handle* h,
+                     uint32_t num_packets, const vsyn_packet* packets,
+                     uint32_t num_segments, const vsyn_segment* segments,
+                     const uint16_t* ys, const float* residue, size_t residue_floats,
+                     float* pcm, uint64_t plane_stride,
+                     uint32_t* emit_len, const vsyn_taps* taps,
+                     uint32_t flags, vsyn_status* status, const char** err);
+
+/* Waits for hip_stream and returns the accumulated device status since the last call (then clears it). */
+int vsyn_sync_status(vsyn_handle* h, void* hip_stream, vsyn_status* status, const char** err);
+
+/* Forget all overlap state (every stream slot behaves as VSYN_SEG_RESET on its next segment). */
+int vsyn_reset_streams(vsyn_handle* h, void* hip_stream, const char** err);
+
+/* Kernel timing for roofline reporting: when enabled, vsyn_submit_device brackets its dominant kernel with
+ * hipEvents on hip_stream; vsyn_profile_read synchronises and returns the mean duration since the last read. */
+int vsyn_profile_enable(vsyn_handle* h, int on);
+int vsyn_profile_read(vsyn_handle* h, double* mean_ms, uint32_t* launches, const char** kernel_name);
+
+/* IMDCT-only entry (BASELINE config 2): in [count][n/2] -> out [count][n], device pointers, n = blocksize0 or blocksize1. */
+int vsyn_imdct_device(vsyn_handle* h, uint32_t n, uint32_t count, const float* d_in, float* d_out,
+                      void* hip_stream, const char** err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORBIS_SYNTH_HIP_H_ */

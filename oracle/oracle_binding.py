@@ -1,0 +1,157 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so) and, when present, the reference shim
+(oracle/_ref/libref_shim.so).  TEST INFRASTRUCTURE: import only from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(_HERE, "liboracle.so")
+REF_SHIM = os.path.join(_HERE, "_ref", "libref_shim.so")
+REF_BIN = os.path.join(_HERE, "_ref", "ours.bin")
+
+import sys
+sys.path.insert(0, os.path.dirname(_HERE))
+from parseoggvorbis_amd.binding import (PACKET_DTYPE, SEGMENT_DTYPE, Setup, Status, Taps)  # POD layouts only
+
+_orc = None
+_ref = None
+
+
+def build_oracle():
+    """gcc the restatement (seconds). Safe to call repeatedly."""
+    subprocess.run(["make", "-s", "-C", _HERE, "liboracle.so"], check=True)
+
+
+def oracle():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_LIB):
+            build_oracle()
+        lib = C.CDLL(ORACLE_LIB)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        lib.orc_low_neighbor.argtypes = [vp, C.c_int]
+        lib.orc_high_neighbor.argtypes = [vp, C.c_int]
+        lib.orc_render_point.argtypes = [u32] * 5
+        lib.orc_render_point.restype = u32
+        lib.orc_render_line.argtypes = [C.c_size_t, u32, C.c_size_t, u32, vp, C.c_size_t]
+        lib.orc_render_line.restype = None
+        lib.orc_inverse_db_table.restype = C.POINTER(C.c_float)
+        lib.orc_floor1_synth.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp]
+        lib.orc_inverse_coupling.argtypes = [vp, vp, C.c_size_t]
+        lib.orc_inverse_coupling.restype = None
+        lib.orc_mdct_new.argtypes = [C.c_int]
+        lib.orc_mdct_new.restype = vp
+        lib.orc_mdct_free.argtypes = [vp]
+        lib.orc_mdct_free.restype = None
+        lib.orc_mdct_backward.argtypes = [vp, vp, vp]
+        lib.orc_mdct_backward.restype = None
+        lib.orc_mdct_trig.argtypes = [vp]
+        lib.orc_mdct_trig.restype = C.POINTER(C.c_float)
+        lib.orc_mdct_bitrev.argtypes = [vp]
+        lib.orc_mdct_bitrev.restype = C.POINTER(C.c_int)
+        lib.orc_imdct_closed_form.argtypes = [C.c_int, vp, vp]
+        lib.orc_imdct_closed_form.restype = None
+        lib.orc_imdct_batch.argtypes = [C.c_int, u32, vp, vp]
+        lib.orc_imdct_batch.restype = None
+        lib.orc_window.argtypes = [C.c_int] * 5 + [vp]
+        lib.orc_window.restype = None
+        lib.orc_create.argtypes = [C.POINTER(Setup), u32]
+        lib.orc_create.restype = vp
+        lib.orc_destroy.argtypes = [vp]
+        lib.orc_destroy.restype = None
+        lib.orc_ys_stride.argtypes = [vp]
+        lib.orc_ys_stride.restype = u32
+        lib.orc_reset_streams.argtypes = [vp]
+        lib.orc_reset_streams.restype = None
+        lib.orc_submit.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, u64, vp, C.POINTER(Taps), C.POINTER(Status)]
+        _orc = lib
+    return _orc
+
+
+def have_ref():
+    return os.path.exists(REF_SHIM)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SHIM)
+        vp, u32 = C.c_void_p, C.c_uint32
+        lib.ref_mdct_backward.argtypes = [C.c_int, vp, vp]
+        lib.ref_mdct_backward.restype = None
+        lib.ref_mdct_backward_batch.argtypes = [C.c_int, u32, vp, vp]
+        lib.ref_mdct_backward_batch.restype = None
+        lib.ref_mdct_tables.argtypes = [C.c_int, vp, vp]
+        lib.ref_mdct_tables.restype = None
+        lib.ref_window.argtypes = [C.c_int] * 5 + [vp]
+        lib.ref_low_neighbor.argtypes = [vp, C.c_int, C.c_int]
+        lib.ref_high_neighbor.argtypes = [vp, C.c_int, C.c_int]
+        lib.ref_render_point.argtypes = [u32] * 5
+        lib.ref_render_point.restype = u32
+        lib.ref_render_line.argtypes = [u32, u32, u32, u32, vp, u32]
+        lib.ref_render_line.restype = None
+        lib.ref_inverse_db_table.restype = C.POINTER(C.c_float)
+        lib.ref_overlap_add.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint64, vp,
+                                        C.POINTER(C.c_int)]
+        lib.ref_floor1_synth.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+        _ref = lib
+    return _ref
+
+
+def p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class OracleSynth:
+    """Same surface as parseoggvorbis_amd.binding.Synth.submit_host, computed by the CPU oracle."""
+
+    def __init__(self, spec, max_streams=64):
+        self.lib = oracle()
+        self.spec = spec
+        self._su = spec.c_setup()
+        self.h = self.lib.orc_create(C.byref(self._su), max_streams)
+        assert self.h, "orc_create failed"
+        self.channels = spec.channels
+        self.ys_stride = self.lib.orc_ys_stride(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        self.lib.orc_reset_streams(self.h)
+
+    def submit_host(self, packets, segments, ys, residue, plane_stride, want_taps=False):
+        P, S, Cn = len(packets), len(segments), self.channels
+        packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
+        segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
+        ys = np.ascontiguousarray(ys, dtype=np.uint16)
+        residue = np.ascontiguousarray(residue, dtype=np.float32)
+        pcm = np.zeros((S, Cn, plane_stride), np.float32)
+        emit = np.zeros(P, np.uint32)
+        taps, tp = None, None
+        if want_taps:
+            taps = dict(after_envelope=np.zeros(residue.size, np.float32),
+                        pcm_after_mdct=np.zeros(residue.size * 2, np.float32),
+                        floor_final=np.zeros(ys.size, np.uint16))
+            tp = Taps(taps["after_envelope"].ctypes.data, taps["pcm_after_mdct"].ctypes.data,
+                      taps["floor_final"].ctypes.data)
+        st = Status()
+        rc = self.lib.orc_submit(self.h, P, p(packets), S, p(segments), p(ys), p(residue), p(pcm), plane_stride,
+                                 p(emit), C.byref(tp) if tp else None, C.byref(st))
+        return dict(rc=rc, pcm=pcm, emit_len=emit, taps=taps, flags=st.flags, first_bad=st.first_bad_packet)
+
+
+def imdct(n, x):
+    """x [count][n/2] float32 -> [count][n] via the oracle restatement."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, n // 2)
+    out = np.empty((x.shape[0], n), np.float32)
+    oracle().orc_imdct_batch(n, x.shape[0], p(x), p(out))
+    return out

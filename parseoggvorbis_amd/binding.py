@@ -1,0 +1,243 @@
+"""ctypes view of the C-ABI in include/vorbis_synth_hip.h (libvorbis_synth_hip.so).
+
+Plumbing only: POD struct mirrors, the symbol table and a loader that FAILS LOUDLY when the HIP
+library is missing.  There is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvorbis_synth_hip.so")
+
+VSYN_MAX_CHANNELS = 32
+VSYN_MAX_POSTS = 65
+VSYN_OK, VSYN_ERR_INVALID, VSYN_ERR_NO_DEVICE, VSYN_ERR_HIP, VSYN_ERR_STREAM = 0, 1, 2, 3, 4
+VSYN_ST_FLOOR_RANGE, VSYN_ST_FLOOR_VALUE, VSYN_ST_GRANULE, VSYN_ST_PLANE_OVERFLOW, VSYN_ST_BAD_MODE = 1, 2, 4, 8, 16
+VSYN_SEG_RESET = 1
+VSYN_SUBMIT_STAGED = 1
+
+
+class Floor1(C.Structure):
+    _fields_ = [("multiplier", C.c_uint32), ("num_posts", C.c_uint32), ("xs", C.POINTER(C.c_uint32))]
+
+
+class Coupling(C.Structure):
+    _fields_ = [("magnitude", C.c_uint16), ("angle", C.c_uint16)]
+
+
+class Mapping(C.Structure):
+    _fields_ = [("num_couplings", C.c_uint32), ("couplings", C.POINTER(Coupling)),
+                ("channel_floor", C.POINTER(C.c_uint8))]
+
+
+class Mode(C.Structure):
+    _fields_ = [("block_flag", C.c_uint8), ("mapping", C.c_uint8)]
+
+
+class Setup(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("blocksize0", C.c_uint32), ("blocksize1", C.c_uint32),
+                ("num_floors", C.c_uint32), ("floors", C.POINTER(Floor1)),
+                ("num_mappings", C.c_uint32), ("mappings", C.POINTER(Mapping)),
+                ("num_modes", C.c_uint32), ("modes", C.POINTER(Mode))]
+
+
+class Taps(C.Structure):
+    _fields_ = [("after_envelope", C.c_void_p), ("pcm_after_mdct", C.c_void_p), ("floor_final", C.c_void_p)]
+
+
+class Status(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("first_bad_packet", C.c_uint32)]
+
+
+# numpy record layouts of the batch PODs (sizes asserted against the header's comments)
+PACKET_DTYPE = np.dtype([("mode", "u1"), ("prev_long", "u1"), ("next_long", "u1"), ("reserved0", "u1"),
+                         ("floor_used", "<u4"), ("granule", "<i8")], align=True)
+SEGMENT_DTYPE = np.dtype([("stream", "<u4"), ("first_packet", "<u4"), ("num_packets", "<u4"), ("flags", "<u4"),
+                          ("residue_off", "<u8")], align=True)
+assert PACKET_DTYPE.itemsize == 16 and SEGMENT_DTYPE.itemsize == 24
+
+
+class SetupSpec:
+    """Plain-python description of a stream setup; `.c_setup()` builds the vsyn_setup tree (keeps it alive)."""
+
+    def __init__(self, channels, blocksize0, blocksize1, floors, mappings, modes):
+        # floors: list of (multiplier, xs list); mappings: list of (couplings [(mag,ang)], channel_floor list)
+        # modes: list of (block_flag, mapping)
+        self.channels, self.blocksize0, self.blocksize1 = channels, blocksize0, blocksize1
+        self.floors, self.mappings, self.modes = floors, mappings, modes
+        self._keep = []
+
+    def c_setup(self):
+        keep = []
+        fl = (Floor1 * len(self.floors))()
+        for i, (mult, xs) in enumerate(self.floors):
+            arr = (C.c_uint32 * len(xs))(*xs)
+            keep.append(arr)
+            fl[i].multiplier, fl[i].num_posts, fl[i].xs = mult, len(xs), arr
+        mp = (Mapping * len(self.mappings))()
+        for i, (coups, chfloor) in enumerate(self.mappings):
+            ca = (Coupling * max(1, len(coups)))()
+            for k, (m, a) in enumerate(coups):
+                ca[k].magnitude, ca[k].angle = m, a
+            cf = (C.c_uint8 * self.channels)(*chfloor)
+            keep += [ca, cf]
+            mp[i].num_couplings, mp[i].couplings, mp[i].channel_floor = len(coups), ca, cf
+        md = (Mode * len(self.modes))()
+        for i, (bf, m) in enumerate(self.modes):
+            md[i].block_flag, md[i].mapping = bf, m
+        su = Setup(self.channels, self.blocksize0, self.blocksize1, len(self.floors), fl, len(self.mappings), mp,
+                   len(self.modes), md)
+        keep += [fl, mp, md]
+        self._keep.append(keep)
+        return su
+
+    @property
+    def ys_stride(self):
+        return (max(len(xs) for _, xs in self.floors) + 3) & ~3
+
+    def blocksize_of_mode(self, mode):
+        return self.blocksize1 if self.modes[mode][0] else self.blocksize0
+
+
+_SYMBOLS = [
+    "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels",
+    "vsyn_const_block_bytes", "vsyn_submit_device", "vsyn_submit_host", "vsyn_sync_status", "vsyn_reset_streams",
+    "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device",
+]
+
+
+def declared_symbols():
+    return list(_SYMBOLS)
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library. Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP extension missing: %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, cpp = C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_char_p)
+    lib.vsyn_version.restype = C.c_char_p
+    lib.vsyn_abi_version.restype = C.c_int
+    lib.vsyn_create.argtypes = [C.POINTER(Setup), C.c_int, u32, C.POINTER(vp), cpp]
+    lib.vsyn_destroy.argtypes = [vp]
+    lib.vsyn_destroy.restype = None
+    lib.vsyn_ys_stride.argtypes = [vp]
+    lib.vsyn_ys_stride.restype = u32
+    lib.vsyn_channels.argtypes = [vp]
+    lib.vsyn_channels.restype = u32
+    lib.vsyn_const_block_bytes.argtypes = [vp]
+    lib.vsyn_const_block_bytes.restype = C.c_size_t
+    lib.vsyn_submit_device.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, u64, vp, C.POINTER(Taps), u32, vp, cpp]
+    lib.vsyn_submit_host.argtypes = [vp, u32, vp, u32, vp, vp, vp, C.c_size_t, vp, u64, vp, C.POINTER(Taps), u32,
+                                     C.POINTER(Status), cpp]
+    lib.vsyn_sync_status.argtypes = [vp, vp, C.POINTER(Status), cpp]
+    lib.vsyn_reset_streams.argtypes = [vp, vp, cpp]
+    lib.vsyn_profile_enable.argtypes = [vp, C.c_int]
+    lib.vsyn_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32), cpp]
+    lib.vsyn_imdct_device.argtypes = [vp, u32, u32, vp, vp, vp, cpp]
+    _lib = lib
+    return lib
+
+
+class VsynError(RuntimeError):
+    def __init__(self, code, msg, status=None):
+        super().__init__("vsyn error %d: %s" % (code, msg))
+        self.code, self.status = code, status
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Synth:
+    """Owns one vsyn_handle. Thin: every method is one C-ABI call."""
+
+    def __init__(self, spec, device=0, max_streams=64):
+        self.lib = load()
+        self.spec = spec
+        self._su = spec.c_setup()
+        h, err = C.c_void_p(), C.c_char_p()
+        rc = self.lib.vsyn_create(C.byref(self._su), device, max_streams, C.byref(h), C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
+        self.h = h
+        self.channels = spec.channels
+        self.ys_stride = self.lib.vsyn_ys_stride(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vsyn_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self, stream=None):
+        err = C.c_char_p()
+        rc = self.lib.vsyn_reset_streams(self.h, stream, C.byref(err))
+        if rc:
+            raise VsynError(rc, (err.value or b"").decode())
+
+    def submit_host(self, packets, segments, ys, residue, plane_stride, want_taps=False, flags=0):
+        """numpy in, numpy out: returns dict(pcm [S][C][plane_stride], emit_len [P], taps..., status)."""
+        P, S, Cn = len(packets), len(segments), self.channels
+        packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
+        segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
+        ys = np.ascontiguousarray(ys, dtype=np.uint16)
+        residue = np.ascontiguousarray(residue, dtype=np.float32)
+        assert ys.size == P * Cn * self.ys_stride
+        pcm = np.zeros((S, Cn, plane_stride), np.float32)
+        emit = np.zeros(P, np.uint32)
+        taps, tp = None, None
+        if want_taps:
+            taps = dict(after_envelope=np.zeros(residue.size, np.float32),
+                        pcm_after_mdct=np.zeros(residue.size * 2, np.float32),
+                        floor_final=np.zeros(ys.size, np.uint16))
+            tp = Taps(taps["after_envelope"].ctypes.data, taps["pcm_after_mdct"].ctypes.data,
+                      taps["floor_final"].ctypes.data)
+        st, err = Status(), C.c_char_p()
+        rc = self.lib.vsyn_submit_host(self.h, P, _ptr(packets), S, _ptr(segments), _ptr(ys), _ptr(residue),
+                                       residue.size, _ptr(pcm), plane_stride, _ptr(emit),
+                                       C.byref(tp) if tp else None, flags, C.byref(st), C.byref(err))
+        if rc not in (VSYN_OK, VSYN_ERR_STREAM):
+            raise VsynError(rc, (err.value or b"").decode())
+        return dict(rc=rc, pcm=pcm, emit_len=emit, taps=taps, flags=st.flags, first_bad=st.first_bad_packet)
+
+    def submit_device(self, P, d_packets, S, d_segments, max_seg_packets, d_ys, d_residue, d_pcm, plane_stride,
+                      d_emit=None, taps=None, flags=0, stream=None):
+        """All arguments are raw device addresses (ints)."""
+        err = C.c_char_p()
+        tp = C.byref(Taps(*taps)) if taps else None
+        rc = self.lib.vsyn_submit_device(self.h, P, d_packets, S, d_segments, max_seg_packets, d_ys, d_residue,
+                                         d_pcm, plane_stride, d_emit, tp, flags, stream, C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
+
+    def sync_status(self, stream=None):
+        st, err = Status(), C.c_char_p()
+        rc = self.lib.vsyn_sync_status(self.h, stream, C.byref(st), C.byref(err))
+        if rc not in (VSYN_OK, VSYN_ERR_STREAM):
+            raise VsynError(rc, (err.value or b"").decode())
+        return st.flags, st.first_bad_packet
+
+    def imdct_device(self, n, count, d_in, d_out, stream=None):
+        err = C.c_char_p()
+        rc = self.lib.vsyn_imdct_device(self.h, n, count, d_in, d_out, stream, C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
+
+    def profile(self, on=True):
+        self.lib.vsyn_profile_enable(self.h, 1 if on else 0)
+
+    def profile_read(self):
+        ms, n, name = C.c_double(), C.c_uint32(), C.c_char_p()
+        self.lib.vsyn_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(name))
+        return ms.value, n.value, (name.value or b"").decode()

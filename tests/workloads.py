@@ -1,0 +1,153 @@
+"""Shared inputs for tests and bench: the committed golden fixtures and the seeded synthetic batches of
+BASELINE.json's configs.  numpy only."""
+import os
+
+import numpy as np
+
+from parseoggvorbis_amd.binding import PACKET_DTYPE, SEGMENT_DTYPE, VSYN_SEG_RESET, SetupSpec
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# floor-1 X lists of the reference's fixtures (hook "floor1_unpack xs", hpp:1367)
+FIX_XS_SHORT = [0, 128, 14, 4, 58, 2, 8, 28, 90]
+FIX_XS_LONG_SORTED = [0, 3, 6, 10, 14, 18, 23, 28, 33, 39, 46, 55, 65, 79, 93, 111, 130, 158, 186, 220, 260, 312, 372,
+                      464, 556, 650, 750, 850, 1024]
+
+
+def load_golden(name):
+    """-> (SetupSpec, dict of arrays, npz) for 'test.stereo44khz' / 'test.mono44khz'."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    C = int(z["channels"])
+    floors = [(int(z["floor%d_mult" % f]), [int(v) for v in z["floor%d_xs" % f]]) for f in range(int(z["num_floors"]))]
+    coup = [(0, 1)] if C == 2 else []
+    # fixtures: mode 0 short -> mapping 0 -> floor 0, mode 1 long -> mapping 1 -> floor 1
+    spec = SetupSpec(C, int(z["blocksize0"]), int(z["blocksize1"]), floors,
+                     [(coup, [0] * C), (coup, [1] * C)], [(0, 0), (1, 1)])
+    P = len(z["mode"])
+    assert np.array_equal(z["floor_number"], np.repeat(z["mode"][:, None], C, 1))
+    pk = np.zeros(P, PACKET_DTYPE)
+    pk["mode"], pk["prev_long"], pk["next_long"] = z["mode"], z["prev_long"], z["next_long"]
+    pk["floor_used"], pk["granule"] = z["floor_used"], z["granule"]
+    seg = np.zeros(1, SEGMENT_DTYPE)
+    seg["num_packets"], seg["flags"] = P, VSYN_SEG_RESET
+    return spec, dict(packets=pk, segments=seg, ys=z["ys"], residue=z["residue"], pcm=z["pcm"],
+                      emit_len=z["emit_len"]), z
+
+
+def fixture_like_spec(channels=2, bs0=256, bs1=2048):
+    """The fixtures' stream setup, generalised to other blocksizes by scaling the X lists."""
+    def scale(xs, n2, base):
+        out = sorted({min(n2, max(0, (x * n2) // base)) for x in xs})
+        if len(out) < 2:
+            out = [0, n2]
+        out = [0, n2] + [x for x in out if x not in (0, n2)]
+        return out
+    short = scale(FIX_XS_SHORT, bs0 // 2, 128)
+    long_sorted = scale(FIX_XS_LONG_SORTED, bs1 // 2, 1024)
+    rng = np.random.default_rng(99)
+    inner = long_sorted[2:]
+    rng.shuffle(inner)  # header order is not sorted in real streams
+    long_ = [0, bs1 // 2] + [int(v) for v in inner]
+    coup = [(0, 1)] if channels >= 2 else []
+    return SetupSpec(channels, bs0, bs1, [(4, short), (2, long_)],
+                     [(coup, [0] * channels), (coup, [1] * channels)], [(0, 0), (1, 1)])
+
+
+def _encode_ys(xs, mult, target, rng, zero_frac):
+    """Coded floor-1 ys whose unwrap gives (approximately) `target` amplitudes; always in range (valid stream)."""
+    rng_of = {1: 256, 2: 128, 3: 86, 4: 64}[mult]
+    posts = len(xs)
+    ys = np.zeros(posts, np.int64)
+    fy = np.zeros(posts, np.int64)
+    lo_n = [max([j for j in range(i) if xs[j] < xs[i]], key=lambda j: xs[j], default=-1) for i in range(posts)]
+    hi_n = [min([j for j in range(i) if xs[j] > xs[i]], key=lambda j: xs[j], default=-1) for i in range(posts)]
+    fy[0] = ys[0] = min(rng_of - 1, max(0, int(target[0])))
+    fy[1] = ys[1] = min(rng_of - 1, max(0, int(target[1])))
+    for i in range(2, posts):
+        lo, hi = lo_n[i], hi_n[i]
+        adx = xs[hi] - xs[lo]
+        dy = fy[hi] - fy[lo]
+        off = (abs(dy) * (xs[i] - xs[lo])) // adx
+        pred = fy[lo] + off if dy >= 0 else fy[lo] - off
+        d = min(rng_of - 1, max(0, int(target[i]))) - pred
+        hr, lr = rng_of - pred, pred
+        room = min(hr, lr) * 2
+        val = 0
+        if d != 0 and rng.random() >= zero_frac:
+            if d > 0:
+                val = 2 * d if 2 * d < room else (d + lr if hr > lr else 0)
+            else:
+                val = -2 * d - 1 if -2 * d - 1 < room else (hr - d - 1 if hr <= lr else 0)
+        if val == 0:
+            f = pred
+        elif val >= room:
+            f = val - lr + pred if hr > lr else pred - val + hr - 1
+        else:
+            f = pred - (val + 1) // 2 if val % 2 else pred + val // 2
+        if not (0 <= f < rng_of):
+            val, f = 0, pred
+        ys[i], fy[i] = val, f
+    return ys
+
+
+def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, ylo=40, yhi=100, unused_frac=0.0,
+                granule_last=False):
+    """Synthetic batch in the shape of BASELINE configs 3/4:
+    residue = round(Laplace(b=1.5)) with 60 % zeros; floor amplitudes a random walk in [ylo,yhi] (step +-6)
+    over the setup's X list, wrapped into coded ys.  pattern: 'long', 'short' or 'mixed' (L L L S*8 repeating).
+    Returns dict(packets, segments, ys, residue, plane_stride)."""
+    rng = np.random.default_rng(seed)
+    C = spec.channels
+    if pattern == "long":
+        flags1 = np.ones(packets_per_stream, np.uint8)
+    elif pattern == "short":
+        flags1 = np.zeros(packets_per_stream, np.uint8)
+    else:
+        unit = [1, 1, 1] + [0] * 8
+        flags1 = np.array((unit * (packets_per_stream // len(unit) + 1))[:packets_per_stream], np.uint8)
+    long_mode = [i for i, (bf, _) in enumerate(spec.modes) if bf][0]
+    short_mode = [i for i, (bf, _) in enumerate(spec.modes) if not bf][0]
+    P = streams * packets_per_stream
+    pk = np.zeros(P, PACKET_DTYPE)
+    seg = np.zeros(streams, SEGMENT_DTYPE)
+    stride = spec.ys_stride
+    ys = np.zeros((P, C, stride), np.uint16)
+    res_parts = []
+    off = 0
+    for s in range(streams):
+        flags = flags1 if pattern != "mixed" else np.roll(flags1, s % 11)
+        seg[s] = (s, s * packets_per_stream, packets_per_stream, VSYN_SEG_RESET, off)
+        for q in range(packets_per_stream):
+            p = s * packets_per_stream + q
+            lng = int(flags[q])
+            mode = long_mode if lng else short_mode
+            n = spec.blocksize1 if lng else spec.blocksize0
+            pk[p]["mode"] = mode
+            if lng:
+                pk[p]["prev_long"] = flags[q - 1] if q > 0 else 1
+                pk[p]["next_long"] = flags[q + 1] if q + 1 < packets_per_stream else 1
+            pk[p]["granule"] = -1
+            used = 0
+            for c in range(C):
+                if rng.random() < unused_frac:
+                    continue
+                used |= 1 << c
+                mult, xs = spec.floors[spec.mappings[spec.modes[mode][1]][1][c]]
+                order = np.argsort(xs)
+                walk = np.clip(np.cumsum(rng.integers(-6, 7, len(xs))) + rng.integers(ylo, yhi), ylo, yhi)
+                target = np.zeros(len(xs), np.int64)
+                target[order] = walk * 2 // mult  # same dB range whatever the multiplier
+                ys[p, c, :len(xs)] = _encode_ys(xs, mult, target, rng, 0.25)
+            pk[p]["floor_used"] = used
+            r = np.round(rng.laplace(0.0, 1.5, (C, n // 2)))
+            r[rng.random((C, n // 2)) < 0.6] = 0
+            res_parts.append(r.astype(np.float32).ravel())
+            off += C * (n // 2)
+    if granule_last:
+        for s in range(streams):
+            fl = flags1 if pattern != "mixed" else np.roll(flags1, s % 11)
+            sizes = np.where(fl, spec.blocksize1, spec.blocksize0)
+            total = int(sum(sizes[i - 1] // 4 + sizes[i] // 4 for i in range(1, packets_per_stream)))
+            pk[s * packets_per_stream + packets_per_stream - 1]["granule"] = max(0, total - 37)
+    plane = packets_per_stream * (spec.blocksize1 // 2) + 64
+    return dict(packets=pk, segments=seg, ys=ys, residue=np.concatenate(res_parts), plane_stride=plane)
