@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric: audio packets/s of the batched spectral-synthesis hot path.
+
+A step = one pass of the hot path (layout + floor unwrap + fused floor-render/coupling/IMDCT/window/overlap-add)
+over one device-resident synthetic batch: BASELINE config 3, 65 536 stereo packets, blocksize 2048, as 64
+streams x 1024 packets, per GPU (weak scaling: every rank owns its own streams; no data-path
+collective — streams are independent, hpp:1117-1123).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def alg_bytes_per_packet(spec, n, posts):
+    """per stereo packet, residue in + coded posts in + PCM out once."""
+    C = spec.channels
+    return C * ((n // 2) * 4 + posts * 2 + (n // 2) * 4)
+
+
+def build_batch(spec, streams, ppk, pattern, seed, device):
+    """Device-resident synthetic batch; value distributions as tests/workloads.synth_batch."""
+    import torch
+    from parseoggvorbis_amd.binding import PACKET_DTYPE, SEGMENT_DTYPE, VSYN_SEG_RESET
+    from tests.workloads import synth_batch
+    C = spec.channels
+    # coded floor rows: a pool of valid rows made on the host (the unwrap chain is serial per row), tiled on device
+    pool_pk = 64 if pattern != "mixed" else 66
+    pool = synth_batch(spec, 4, pool_pk, pattern, seed=seed)
+    P = streams * ppk
+    pk = np.zeros(P, PACKET_DTYPE)
+    seg = np.zeros(streams, SEGMENT_DTYPE)
+    pool_n = len(pool["packets"]) // 4  # packets per pool stream (same flag pattern per stream when not rolled)
+    reps = (ppk + pool_n - 1) // pool_n
+    one = np.concatenate([pool["packets"][:pool_n]] * reps)[:ppk].copy()
+    one["granule"] = -1
+    if pattern == "mixed":  # re-derive consistent window flags after tiling
+        lng = one["mode"] == [i for i, (bf, _) in enumerate(spec.modes) if bf][0]
+        one["prev_long"] = np.where(lng, np.concatenate([[1], lng[:-1]]), 0)
+        one["next_long"] = np.where(lng, np.concatenate([lng[1:], [1]]), 0)
+    n_of = np.where(one["mode"] == [i for i, (bf, _) in enumerate(spec.modes) if bf][0], spec.blocksize1, spec.blocksize0)
+    per_stream_floats = int((C * n_of // 2).sum())
+    for s in range(streams):
+        pk[s * ppk:(s + 1) * ppk] = one
+        seg[s] = (s, s * ppk, ppk, VSYN_SEG_RESET, s * per_stream_floats)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    # ys rows: tile the pool's rows packet-wise (row q of every stream = pool row q mod pool_n, stream-varied)
+    ys_pool = torch.from_numpy(pool["ys"].astype(np.int16)).to(device)  # [4*pool_n][C][stride]
+    idx = (torch.arange(ppk, device=device) % pool_n)[None, :] + pool_n * torch.randint(0, 4, (streams, 1), device=device, generator=g)
+    ys = ys_pool[idx.reshape(-1)].contiguous()
+    total = streams * per_stream_floats
+    u = torch.rand(total, device=device, generator=g)
+    v = torch.rand(total, device=device, generator=g)
+    lap = -1.5 * torch.sign(u - 0.5) * torch.log1p(-2 * (u - 0.5).abs().clamp(max=0.4999999))
+    res = torch.where(v < 0.6, torch.zeros_like(lap), torch.round(lap)).contiguous()
+    del u, v, lap
+    plane = int(sum(int(n_of[i - 1]) // 4 + int(n_of[i]) // 4 for i in range(1, ppk))) + 64
+    plane = (plane + 63) // 64 * 64
+    return dict(P=P, S=streams, ppk=ppk, packets=torch.from_numpy(pk.view(np.uint8)).to(device),
+                segments=torch.from_numpy(seg.view(np.uint8)).to(device), ys=ys, residue=res, plane=plane,
+                host_packets=pk, host_segments=seg, per_stream_floats=per_stream_floats, n_of=n_of)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config2"])
+    ap.add_argument("--streams", type=int, default=64)
+    ap.add_argument("--packets-per-stream", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--staged", action="store_true", help="time the staged kernels instead of the fused one")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, "launch with WORLD_SIZE == --gpus (one process per GPU)"
+
+    from parseoggvorbis_amd.binding import Synth, VSYN_SUBMIT_STAGED
+    from tests.workloads import fixture_like_spec
+
+    # rank 0 owns the stream setup; ONE broadcast of the (tiny) setup block splits the job, then ranks are independent
+    spec = fixture_like_spec(2 if args.workload != "config2" else 1)
+    blob = np.array([spec.channels, spec.blocksize0, spec.blocksize1] + [len(spec.floors[0][1])] + spec.floors[0][1] +
+                    [len(spec.floors[1][1])] + spec.floors[1][1], np.int32)
+    if world > 1:
+        t = torch.from_numpy(blob).to(device) if rank == 0 else torch.zeros(len(blob), dtype=torch.int32, device=device)
+        dist.broadcast(t, 0)
+        assert np.array_equal(t.cpu().numpy(), blob)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = VSYN_SUBMIT_STAGED if args.staged else 0
+
+    if args.workload == "config2":
+        n, count = 256, 4096
+        gpu = Synth(spec, device=local, max_streams=1)
+        g = torch.Generator(device=device)
+        g.manual_seed(1234 + rank)
+        x = (torch.randn((count, n // 2), device=device, generator=g) * 0.05).contiguous()
+        y = torch.zeros((count, n), device=device)
+        step = lambda: gpu.imdct_device(n, count, x.data_ptr(), y.data_ptr(), stream)
+        units, bytes_per_unit, wl = count, 1536, "config2: 4096 mono packets, blocksize 256, IMDCT only"
+        b = None
+    else:
+        pattern = "long" if args.workload == "config3" else "mixed"
+        ppk = args.packets_per_stream or (1024 if args.workload == "config3" else 512)
+        b = build_batch(spec, args.streams, ppk, pattern, 1234 + rank, device)
+        gpu = Synth(spec, device=local, max_streams=args.streams)
+        pcm = torch.zeros((b["S"], spec.channels, b["plane"]), device=device)
+        emit = torch.zeros(b["P"], dtype=torch.int32, device=device)
+        step = lambda: gpu.submit_device(b["P"], b["packets"].data_ptr(), b["S"], b["segments"].data_ptr(), b["ppk"],
+                                         b["ys"].data_ptr(), b["residue"].data_ptr(), pcm.data_ptr(), b["plane"],
+                                         emit.data_ptr(), None, flags, stream)
+        units = b["P"]
+        posts = {0: len(spec.floors[0][1]), 1: len(spec.floors[1][1])}
+        lng_frac = float((b["n_of"] == spec.blocksize1).mean())
+        # algorithmic bytes / packet: residue in + coded posts in + emitted PCM out
+        in_b = float(np.mean([spec.channels * ((int(n) // 2) * 4 + posts[int(n == spec.blocksize1)] * 2) for n in b["n_of"]]))
+        out_b = spec.channels * 4.0 * (b["plane"] - 64) / ppk
+        bytes_per_unit = in_b + out_b
+        wl = ("config3: %d stereo packets, blocksize 2048, %d streams x %d, floor+coupling+IMDCT+window+overlap-add"
+              % (b["P"], b["S"], ppk)) if pattern == "long" else \
+             ("config4: %d stereo packets, mixed 2048/256 (%.0f%% long), %d streams x %d" % (b["P"], 100 * lng_frac, b["S"], ppk))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    fl, bad = gpu.sync_status(stream)
+    assert fl == 0, "device flagged the synthetic batch: 0x%x at packet %d" % (fl, bad)
+
+    gpu.profile(True)
+    gpu.profile_read()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, launches, kern_name = gpu.profile_read()
+    gpu.profile(False)
+
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cnt = torch.tensor([units], device=device, dtype=torch.int64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_units = int(cnt.item())
+    else:
+        total_units = units
+
+    # parity spot check against the CPU oracle on the first streams of this rank's batch (not timed)
+    max_err, cpu = None, None
+    if b is not None and rank == 0:
+        from oracle.oracle_binding import OracleSynth
+        ns = min(2, b["S"])
+        hp = b["host_packets"][:ns * b["ppk"]]
+        hs = b["host_segments"][:ns].copy()
+        hy = b["ys"][:ns * b["ppk"]].cpu().numpy().view(np.uint16)
+        hr = b["residue"][:ns * b["per_stream_floats"]].cpu().numpy()
+        orc = OracleSynth(spec, ns)
+        want = orc.submit_host(hp, hs, hy, hr, b["plane"])
+        got = pcm[:ns].cpu().numpy()
+        max_err = float(np.abs(got - want["pcm"]).max())
+        pcm_peak = float(np.abs(want["pcm"]).max())
+        assert np.array_equal(emit[:ns * b["ppk"]].cpu().numpy().astype(np.uint32), want["emit_len"])
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU baseline: the oracle (a port of the reference's arithmetic), single thread, bounded sample
+            reps, t_cpu = 0, 0.0
+            while t_cpu < 10.0 and reps < 40:
+                c0 = time.perf_counter()
+                orc.submit_host(hp, hs, hy, hr, b["plane"])
+                t_cpu += time.perf_counter() - c0
+                reps += 1
+            cpu = {"value": round(len(hp) * reps / t_cpu, 1), "unit": "packets/s", "cores": 1, "kind": "port",
+                   "sample": "%d streams x %d packets of the same batch, oracle/liboracle.so (gcc -O2), %d repetitions, %.1f s"
+                             % (ns, b["ppk"], reps, t_cpu)}
+    elif b is None and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_binding as ob
+        hx = x.cpu().numpy()
+        want = ob.imdct(256, hx)
+        max_err = float(np.abs(y.cpu().numpy() - want).max())
+        pcm_peak = float(np.abs(want).max())
+        reps, t_cpu = 0, 0.0
+        while t_cpu < 5.0:
+            c0 = time.perf_counter()
+            ob.imdct(256, hx)
+            t_cpu += time.perf_counter() - c0
+            reps += 1
+        cpu = {"value": round(4096 * reps / t_cpu, 1), "unit": "packets/s", "cores": 1, "kind": "port",
+               "sample": "the same 4096 blocks, %d repetitions, %.1f s" % (reps, t_cpu)}
+
+    if rank == 0:
+        value = total_units * args.steps / dt
+        achieved = bytes_per_unit * units / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+        line = {
+            "metric": "audio packets/sec (blocksize 2048, stereo)" if args.workload == "config3" else "audio packets/sec",
+            "value": round(value, 1), "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "packets_per_gpu": units, "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": kern_name, "kernel_ms": round(kern_ms, 5), "launches": launches,
+                         "algorithmic_bytes_per_packet": round(bytes_per_unit, 1)},
+            "cpu_baseline": cpu,
+            "pcm_max_abs_err_vs_oracle": max_err, "pcm_peak": None if max_err is None else pcm_peak,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,7 +50,8 @@ enum {
   VSYN_ST_FLOOR_VALUE = 1u << 1,   /* rendered floor value >= 256, hpp:587 */
   VSYN_ST_GRANULE = 1u << 2,       /* page granule behind/ahead of what the packets provide, hpp:1029,1041 */
   VSYN_ST_PLANE_OVERFLOW = 1u << 3,/* a segment emits more than plane_stride samples (nothing is written out of bounds) */
-  VSYN_ST_BAD_MODE = 1u << 4       /* mode index >= num_modes */
+  VSYN_ST_BAD_MODE = 1u << 4,      /* mode index >= num_modes */
+  VSYN_ST_BAD_SEGMENT = 1u << 5    /* segment out of range / unknown stream slot / unaligned residue_off */
 };
 
 /* ---- stream setup: the part of VorbisStreamSetup (hpp:889-964) the synthesis half reads ---- */

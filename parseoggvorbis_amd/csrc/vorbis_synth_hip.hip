@@ -1,0 +1,575 @@
+// vorbis_synth_hip.hip — host side of the C-ABI in include/vorbis_synth_hip.h + kernel launches.
+// gfx950 (MI355X) only; built by __graft_entry__.build() with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// No CPU compute path exists in this library: without a HIP device every entry point returns
+// VSYN_ERR_NO_DEVICE.  The only host arithmetic is the once-per-stream constant block (twiddles, windows,
+// floor neighbour tables), which the reference also builds once per stream (mdct.cpp:88-127, hpp:837-862).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vsyn_device.h"
+#include "vsyn_staged.h"
+#include "vsyn_fused.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846264338327
+#endif
+#ifndef M_PI_2
+#define M_PI_2 1.57079632679489661923
+#endif
+
+static const uint32_t k_inverse_db_bits[256] = {
+#include "vorbis_floor1_inverse_db.inc"
+};
+
+namespace {
+
+thread_local char g_err[512];
+
+int fail(const char** err, int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  if (err) *err = g_err;
+  return code;
+}
+
+#define HIPCHK(call)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      return fail(err, VSYN_ERR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {  // grow-only device buffer
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+uint32_t ilog2(uint32_t v) {
+  uint32_t r = 0;
+  while ((1u << r) < v) ++r;
+  return r;
+}
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct vsyn_handle {
+  int device = 0;
+  ConstHeader H{};
+  std::vector<uint8_t> host_const;
+  uint8_t* d_const = nullptr;
+  StreamState* d_state = nullptr;
+  float* d_carry = nullptr;
+  DevStatus* d_status = nullptr;
+  FusedTables fused{};
+  // workspace
+  DevBuf<PktInfo> ws_info;
+  DevBuf<SegInfo> ws_seg;
+  DevBuf<uint32_t> ws_segmap;
+  DevBuf<uint16_t> ws_fy;
+  DevBuf<float> ws_env, ws_blk;
+  // host-submit staging
+  DevBuf<vsyn_packet> st_pk;
+  DevBuf<vsyn_segment> st_seg;
+  DevBuf<uint16_t> st_ys, st_fy;
+  DevBuf<float> st_res, st_pcm, st_env, st_blk;
+  DevBuf<uint32_t> st_emit;
+  // profiling
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  const char* profile_kernel = "";
+  std::mutex mu;
+};
+
+// ------------------------------------------------------------------------------------------------
+// constant block
+// ------------------------------------------------------------------------------------------------
+static void host_window(uint32_t bs0, uint32_t bs1, int lng, int prev, int next, float* w) {
+  // VorbisModeNumber::precalc, hpp:837-862 (same float/double mix: sinf of a double-computed argument)
+  const uint32_t n = lng ? bs1 : bs0;
+  if (!lng) prev = next = 0;
+  const uint32_t left = (prev ? bs1 : bs0) / 2, right = (next ? bs1 : bs0) / 2;
+  const uint32_t left_begin = n / 4 - left / 2, right_begin = n - n / 4 - right / 2;
+  for (uint32_t i = 0; i < n; ++i) w[i] = 0.f;
+  for (uint32_t i = 0; i < left; ++i) {
+    float x = sinf((float)(M_PI_2 * (i + 0.5) / left));
+    w[left_begin + i] = sinf((float)(M_PI_2 * x * x));
+  }
+  for (uint32_t i = left_begin + left; i < right_begin; ++i) w[i] = 1.f;
+  for (uint32_t i = 0; i < right; ++i) {
+    float x = sinf((float)(M_PI_2 * (right - i - .5) / right));
+    w[right_begin + i] = sinf((float)(M_PI_2 * x * x));
+  }
+}
+
+static int build_const(const vsyn_setup* su, uint32_t max_streams, vsyn_handle* h, const char** err) {
+  if (!su) return fail(err, VSYN_ERR_INVALID, "setup is NULL");
+  if (su->channels < 1 || su->channels > VSYN_MAX_CHANNELS) return fail(err, VSYN_ERR_INVALID, "channels %u not in 1..%d", su->channels, VSYN_MAX_CHANNELS);
+  if (!is_pow2(su->blocksize0) || !is_pow2(su->blocksize1) || su->blocksize0 < VSYN_MIN_BLOCKSIZE ||
+      su->blocksize1 > VSYN_MAX_BLOCKSIZE || su->blocksize0 > su->blocksize1)
+    return fail(err, VSYN_ERR_INVALID, "blocksizes %u/%u invalid (hpp:1294-1298)", su->blocksize0, su->blocksize1);
+  if (su->num_floors < 1 || su->num_floors > VSYN_MAX_TABLES || su->num_mappings < 1 || su->num_mappings > VSYN_MAX_TABLES ||
+      su->num_modes < 1 || su->num_modes > VSYN_MAX_TABLES || !su->floors || !su->mappings || !su->modes)
+    return fail(err, VSYN_ERR_INVALID, "floor/mapping/mode counts out of range");
+  if (max_streams < 1) return fail(err, VSYN_ERR_INVALID, "max_streams must be >= 1");
+
+  ConstHeader& H = h->H;
+  memset(&H, 0, sizeof(H));
+  H.channels = su->channels;
+  H.bs[0] = su->blocksize0;
+  H.bs[1] = su->blocksize1;
+  H.lg[0] = ilog2(su->blocksize0);
+  H.lg[1] = ilog2(su->blocksize1);
+  H.num_floors = su->num_floors;
+  H.num_mappings = su->num_mappings;
+  H.num_modes = su->num_modes;
+  H.max_streams = max_streams;
+
+  std::vector<FloorConst> floors(su->num_floors);
+  uint32_t maxp = 2;
+  for (uint32_t f = 0; f < su->num_floors; ++f) {
+    const vsyn_floor1& sf = su->floors[f];
+    FloorConst& fc = floors[f];
+    memset(&fc, 0, sizeof(fc));
+    if (sf.multiplier < 1 || sf.multiplier > 4) return fail(err, VSYN_ERR_INVALID, "floor %u: multiplier %u (hpp:486-492)", f, sf.multiplier);
+    if (sf.num_posts < 2 || sf.num_posts > VSYN_MAX_POSTS || !sf.xs) return fail(err, VSYN_ERR_INVALID, "floor %u: %u posts", f, sf.num_posts);
+    static const uint32_t range_of[5] = {0, 256, 128, 86, 64};
+    fc.mult = sf.multiplier;
+    fc.posts = sf.num_posts;
+    fc.range = range_of[sf.multiplier];
+    maxp = std::max(maxp, sf.num_posts);
+    for (uint32_t i = 0; i < sf.num_posts; ++i) {
+      if (sf.xs[i] > 0xFFFFu) return fail(err, VSYN_ERR_INVALID, "floor %u: x[%u]=%u too large", f, i, sf.xs[i]);
+      fc.xs[i] = (uint16_t)sf.xs[i];
+    }
+    if (sf.xs[0] != 0) return fail(err, VSYN_ERR_INVALID, "floor %u: xs[0] must be 0 (hpp:449)", f);
+    std::vector<uint32_t> order(sf.num_posts);
+    for (uint32_t i = 0; i < sf.num_posts; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sf.xs[a] < sf.xs[b]; });
+    for (uint32_t s = 0; s < sf.num_posts; ++s) {
+      if (s && sf.xs[order[s]] == sf.xs[order[s - 1]]) return fail(err, VSYN_ERR_INVALID, "floor %u: duplicate x %u (render_line needs x0<x1, Utils.hpp:145)", f, sf.xs[order[s]]);
+      fc.sorted_idx[s] = (uint8_t)order[s];
+      fc.xs_sorted[s] = (uint16_t)sf.xs[order[s]];
+    }
+    for (uint32_t i = 2; i < sf.num_posts; ++i) {  // Utils.hpp:60-118
+      int lo = -1, hi = -1;
+      for (uint32_t j = 0; j < i; ++j) {
+        if (sf.xs[j] < sf.xs[i] && (lo < 0 || sf.xs[j] > sf.xs[lo])) lo = (int)j;
+        if (sf.xs[j] > sf.xs[i] && (hi < 0 || sf.xs[j] < sf.xs[hi])) hi = (int)j;
+      }
+      if (lo < 0 || hi < 0) return fail(err, VSYN_ERR_INVALID, "floor %u: post %u has no low/high neighbour (xs[1] must be the maximum)", f, i);
+      fc.lo[i] = (uint8_t)lo;
+      fc.hi[i] = (uint8_t)hi;
+    }
+  }
+  H.ys_stride = (maxp + 3u) & ~3u;
+
+  std::vector<MapConst> maps(su->num_mappings);
+  for (uint32_t m = 0; m < su->num_mappings; ++m) {
+    const vsyn_mapping& sm = su->mappings[m];
+    MapConst& mc = maps[m];
+    memset(&mc, 0, sizeof(mc));
+    if (sm.num_couplings > 256 || (sm.num_couplings && !sm.couplings) || !sm.channel_floor) return fail(err, VSYN_ERR_INVALID, "mapping %u invalid", m);
+    mc.ncoup = sm.num_couplings;
+    for (uint32_t k = 0; k < sm.num_couplings; ++k) {
+      const vsyn_coupling& c = sm.couplings[k];
+      if (c.magnitude == c.angle || c.magnitude >= su->channels || c.angle >= su->channels)
+        return fail(err, VSYN_ERR_INVALID, "mapping %u coupling %u invalid (hpp:788-790)", m, k);
+      mc.coup[2 * k] = c.magnitude;
+      mc.coup[2 * k + 1] = c.angle;
+    }
+    for (uint32_t c = 0; c < su->channels; ++c) {
+      if (sm.channel_floor[c] >= su->num_floors) return fail(err, VSYN_ERR_INVALID, "mapping %u: floor index out of range (hpp:807)", m);
+      mc.chfloor[c] = sm.channel_floor[c];
+    }
+  }
+  for (uint32_t k = 0; k < su->num_modes; ++k) {
+    if (su->modes[k].mapping >= su->num_mappings) return fail(err, VSYN_ERR_INVALID, "mode %u: mapping out of range (hpp:832)", k);
+    H.mode_blockflag[k] = su->modes[k].block_flag ? 1 : 0;
+    H.mode_mapping[k] = su->modes[k].mapping;
+  }
+
+  // lay the block out
+  size_t off = align_up(sizeof(ConstHeader), 256);
+  H.off_floor = (uint32_t)off;
+  off = align_up(off + sizeof(FloorConst) * floors.size(), 256);
+  H.off_map = (uint32_t)off;
+  off = align_up(off + sizeof(MapConst) * maps.size(), 256);
+  H.off_invdb = (uint32_t)off;
+  off = align_up(off + 256 * sizeof(float), 256);
+  for (int b = 0; b < 2; ++b) {
+    const uint32_t n = H.bs[b];
+    H.off_pre[b] = (uint32_t)off;
+    off = align_up(off + (n / 4) * sizeof(float2), 256);
+    H.off_post[b] = (uint32_t)off;
+    off = align_up(off + (n / 4) * sizeof(float2), 256);
+    H.off_fft[b] = (uint32_t)off;
+    off = align_up(off + (n / 4) * sizeof(float2), 256);
+    H.off_win[b] = (uint32_t)off;
+    off = align_up(off + 4 * (size_t)n * sizeof(float), 256);
+  }
+  H.total_bytes = (uint32_t)off;
+  h->host_const.assign(off, 0);
+  uint8_t* base = h->host_const.data();
+  memcpy(base, &H, sizeof(H));
+  memcpy(base + H.off_floor, floors.data(), sizeof(FloorConst) * floors.size());
+  memcpy(base + H.off_map, maps.data(), sizeof(MapConst) * maps.size());
+  memcpy(base + H.off_invdb, k_inverse_db_bits, sizeof(k_inverse_db_bits));
+  for (int b = 0; b < 2; ++b) {
+    const uint32_t n = H.bs[b], M = n / 2, N4 = n / 4;
+    float2* pre = (float2*)(base + H.off_pre[b]);
+    float2* post = (float2*)(base + H.off_post[b]);
+    float2* tw = (float2*)(base + H.off_fft[b]);
+    for (uint32_t k = 0; k < N4; ++k) {  // double precision, stored as f32 (as mdct_init does)
+      const double a = -M_PI * (4.0 * k + 1.0) / (4.0 * M);
+      pre[k] = make_float2((float)cos(a), (float)sin(a));
+      const double p = -M_PI * (double)k / (double)M;
+      post[k] = make_float2((float)cos(p), (float)sin(p));
+      const double t = -2.0 * M_PI * (double)k / (double)N4;
+      tw[k] = make_float2((float)cos(t), (float)sin(t));
+    }
+    float* win = (float*)(base + H.off_win[b]);
+    for (int w = 0; w < 4; ++w) host_window(H.bs[0], H.bs[1], b, w & 1, (w >> 1) & 1, win + (size_t)w * n);
+  }
+  return VSYN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// API
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* vsyn_version(void) { return "parseoggvorbis_amd vsyn 0.1 (gfx950)"; }
+int vsyn_abi_version(void) { return VSYN_ABI_VERSION; }
+
+int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_handle** out, const char** err) {
+  if (!out) return fail(err, VSYN_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(err, VSYN_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(err, VSYN_ERR_NO_DEVICE, "device %d not in 0..%d", device, ndev - 1);
+  vsyn_handle* h = new vsyn_handle();
+  h->device = device;
+  int rc = build_const(setup, max_streams, h, err);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  auto cleanup = [&](int code) {
+    vsyn_destroy(h);
+    return code;
+  };
+  hipError_t e;
+#define HC(call)                                                                                                       \
+  if ((e = (call)) != hipSuccess) {                                                                                    \
+    fail(err, VSYN_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e));                                             \
+    return cleanup(VSYN_ERR_HIP);                                                                                      \
+  }
+  HC(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HC(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fail(err, VSYN_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return cleanup(VSYN_ERR_NO_DEVICE);
+  }
+  const ConstHeader& H = h->H;
+  HC(hipMalloc((void**)&h->d_const, h->host_const.size()));
+  HC(hipMemcpy(h->d_const, h->host_const.data(), h->host_const.size(), hipMemcpyHostToDevice));
+  HC(hipMalloc((void**)&h->d_state, sizeof(StreamState) * max_streams));
+  HC(hipMemset(h->d_state, 0, sizeof(StreamState) * max_streams));
+  const size_t carry_floats = 2ull * max_streams * H.channels * (H.bs[1] / 2);
+  HC(hipMalloc((void**)&h->d_carry, carry_floats * sizeof(float)));
+  HC(hipMemset(h->d_carry, 0, carry_floats * sizeof(float)));
+  HC(hipMalloc((void**)&h->d_status, sizeof(DevStatus)));
+  DevStatus init = {0u, 0xFFFFFFFFu};
+  HC(hipMemcpy(h->d_status, &init, sizeof(init), hipMemcpyHostToDevice));
+  if ((e = fused_tables_create(h->H, h->host_const.data(), &h->fused)) != hipSuccess) {
+    fail(err, VSYN_ERR_HIP, "fused table upload failed: %s", hipGetErrorString(e));
+    return cleanup(VSYN_ERR_HIP);
+  }
+#undef HC
+  *out = h;
+  return VSYN_OK;
+}
+
+void vsyn_destroy(vsyn_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  fused_tables_destroy(&h->fused);
+  if (h->d_const) (void)hipFree(h->d_const);
+  if (h->d_state) (void)hipFree(h->d_state);
+  if (h->d_carry) (void)hipFree(h->d_carry);
+  if (h->d_status) (void)hipFree(h->d_status);
+  h->ws_info.release(); h->ws_seg.release(); h->ws_segmap.release(); h->ws_fy.release(); h->ws_env.release(); h->ws_blk.release();
+  h->st_pk.release(); h->st_seg.release(); h->st_ys.release(); h->st_fy.release(); h->st_res.release(); h->st_pcm.release();
+  h->st_env.release(); h->st_blk.release(); h->st_emit.release();
+  for (auto& ev : h->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  delete h;
+}
+
+uint32_t vsyn_ys_stride(const vsyn_handle* h) { return h ? h->H.ys_stride : 0; }
+uint32_t vsyn_channels(const vsyn_handle* h) { return h ? h->H.channels : 0; }
+size_t vsyn_const_block_bytes(const vsyn_handle* h) { return h ? h->host_const.size() : 0; }
+
+int vsyn_profile_enable(vsyn_handle* h, int on) {
+  if (!h) return VSYN_ERR_INVALID;
+  h->profile = on != 0;
+  return VSYN_OK;
+}
+
+int vsyn_profile_read(vsyn_handle* h, double* mean_ms, uint32_t* launches, const char** kernel_name) {
+  if (!h) return VSYN_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(h->mu);
+  (void)hipSetDevice(h->device);
+  double total = 0;
+  for (size_t i = 0; i < h->events_used; ++i) {
+    (void)hipEventSynchronize(h->events[i].second);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second);
+    total += ms;
+  }
+  if (mean_ms) *mean_ms = h->events_used ? total / (double)h->events_used : 0.0;
+  if (launches) *launches = (uint32_t)h->events_used;
+  if (kernel_name) *kernel_name = h->profile_kernel;
+  h->events_used = 0;
+  return VSYN_OK;
+}
+
+static hipError_t profile_begin(vsyn_handle* h, hipStream_t s, const char* name) {
+  if (!h->profile) return hipSuccess;
+  if (h->events_used == h->events.size()) {
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&b);
+    if (e != hipSuccess) return e;
+    h->events.emplace_back(a, b);
+  }
+  h->profile_kernel = name;
+  return hipEventRecord(h->events[h->events_used].first, s);
+}
+static hipError_t profile_end(vsyn_handle* h, hipStream_t s) {
+  if (!h->profile) return hipSuccess;
+  hipError_t e = hipEventRecord(h->events[h->events_used].second, s);
+  ++h->events_used;
+  return e;
+}
+
+int vsyn_reset_streams(vsyn_handle* h, void* hip_stream, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemsetAsync(h->d_state, 0, sizeof(StreamState) * h->H.max_streams, (hipStream_t)hip_stream));
+  return VSYN_OK;
+}
+
+int vsyn_sync_status(vsyn_handle* h, void* hip_stream, vsyn_status* status, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+  DevStatus ds;
+  HIPCHK(hipMemcpy(&ds, h->d_status, sizeof(ds), hipMemcpyDeviceToHost));
+  if (ds.flags) {
+    DevStatus init = {0u, 0xFFFFFFFFu};
+    HIPCHK(hipMemcpy(h->d_status, &init, sizeof(init), hipMemcpyHostToDevice));
+  }
+  if (status) {
+    status->flags = ds.flags;
+    status->first_bad_packet = ds.first_bad_packet;
+  }
+  if (ds.flags) return fail(err, VSYN_ERR_STREAM, "device flagged the batch: flags=0x%x first_bad_packet=%u", ds.flags, ds.first_bad_packet);
+  return VSYN_OK;
+}
+
+int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets, uint32_t S, const vsyn_segment* d_segments,
+                       uint32_t max_seg_packets, const uint16_t* d_ys, const float* d_residue, float* d_pcm,
+                       uint64_t plane_stride, uint32_t* d_emit_len, const vsyn_taps* taps, uint32_t flags, void* hip_stream,
+                       const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  if (P == 0 || S == 0) return VSYN_OK;
+  if (!d_packets || !d_segments || !d_ys || !d_residue || !d_pcm) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
+  if (max_seg_packets == 0 || max_seg_packets > P) max_seg_packets = P;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const ConstHeader& H = h->H;
+  const uint32_t C = H.channels;
+  const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct);
+  const bool staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !fused_supported(H);
+
+  HIPCHK(h->ws_info.ensure(P));
+  HIPCHK(h->ws_seg.ensure(S));
+  uint16_t* fy = taps && taps->floor_final ? taps->floor_final : nullptr;
+  if (!fy) {
+    HIPCHK(h->ws_fy.ensure((size_t)P * C * H.ys_stride));
+    fy = h->ws_fy.p;
+  }
+
+  vsyn_layout_kernel<<<S, 256, 0, s>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, h->ws_info.p, h->ws_seg.p,
+                                       h->d_state, d_emit_len, h->d_status);
+  vsyn_floor_unwrap_kernel<<<(P * C + 255) / 256, 256, 0, s>>>(h->d_const, P, h->ws_info.p, d_ys, fy, h->d_status);
+
+  if (!staged) {
+    HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
+    hipError_t e = fused_launch(h->H, h->d_const, h->fused, P, S, d_segments, max_seg_packets, h->ws_info.p, h->ws_seg.p, d_residue, fy,
+                                d_pcm, plane_stride, h->d_carry, h->d_status, s);
+    if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
+    HIPCHK(profile_end(h, s));
+  } else {
+    const size_t bound = (size_t)P * C * (H.bs[1] / 2);  // residue floats upper bound (device-resident descriptors)
+    float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
+    float* blk = taps && taps->pcm_after_mdct ? taps->pcm_after_mdct : nullptr;
+    if (!env) {
+      HIPCHK(h->ws_env.ensure(bound));
+      env = h->ws_env.p;
+    }
+    if (!blk) {
+      HIPCHK(h->ws_blk.ensure(2 * bound));
+      blk = h->ws_blk.p;
+    }
+    HIPCHK(h->ws_segmap.ensure(P));
+    HIPCHK(hipMemsetAsync(h->ws_segmap.p, 0xFF, sizeof(uint32_t) * P, s));
+    vsyn_segmap_kernel<<<dim3(std::min<uint32_t>(64u, (max_seg_packets + 255) / 256), S), 256, 0, s>>>(P, S, d_segments, h->ws_segmap.p);
+    const uint32_t half1 = H.bs[1] / 2;
+    vsyn_spectrum_kernel<<<dim3(P, (half1 + 255) / 256), 256, 0, s>>>(h->d_const, P, h->ws_info.p, d_residue, fy, env, h->d_status);
+    HIPCHK(profile_begin(h, s, "vsyn_imdct_staged_kernel"));
+    vsyn_imdct_staged_kernel<<<P * C, 256, (size_t)H.bs[1] * 4, s>>>(h->d_const, P, h->ws_info.p, env, blk);
+    HIPCHK(profile_end(h, s));
+    vsyn_overlap_kernel<<<dim3(P, C, (half1 + 255) / 256), 256, 0, s>>>(h->d_const, P, h->ws_info.p, S, d_segments, h->ws_seg.p,
+                                                                         h->ws_segmap.p, blk, d_pcm, plane_stride, h->d_carry);
+  }
+  HIPCHK(hipGetLastError());
+  return VSYN_OK;
+}
+
+int vsyn_submit_host(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uint32_t S, const vsyn_segment* segments,
+                     const uint16_t* ys, const float* residue, size_t residue_floats, float* pcm, uint64_t plane_stride,
+                     uint32_t* emit_len, const vsyn_taps* taps, uint32_t flags, vsyn_status* status, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  if (status) {
+    status->flags = 0;
+    status->first_bad_packet = 0xFFFFFFFFu;
+  }
+  if (P == 0 || S == 0) return VSYN_OK;
+  if (!packets || !segments || !ys || !residue || !pcm) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
+  const ConstHeader& H = h->H;
+  const uint32_t C = H.channels;
+  // host-visible validation (the device re-checks everything it dereferences)
+  uint32_t max_seg = 1;
+  for (uint32_t g = 0; g < S; ++g) {
+    const vsyn_segment& sg = segments[g];
+    if (sg.stream >= H.max_streams || (uint64_t)sg.first_packet + sg.num_packets > P || (sg.residue_off & 3))
+      return fail(err, VSYN_ERR_INVALID, "segment %u invalid", g);
+    uint64_t need = sg.residue_off;
+    for (uint32_t q = 0; q < sg.num_packets; ++q) {
+      const uint8_t m = packets[sg.first_packet + q].mode;
+      need += (uint64_t)C * ((m < H.num_modes && H.mode_blockflag[m]) ? H.bs[1] : H.bs[0]) / 2;
+    }
+    if (need > residue_floats) return fail(err, VSYN_ERR_INVALID, "segment %u reads past the residue buffer", g);
+    max_seg = std::max(max_seg, sg.num_packets);
+  }
+  HIPCHK(hipSetDevice(h->device));
+  const size_t ys_n = (size_t)P * C * H.ys_stride, pcm_n = (size_t)S * C * plane_stride;
+  HIPCHK(h->st_pk.ensure(P));
+  HIPCHK(h->st_seg.ensure(S));
+  HIPCHK(h->st_ys.ensure(ys_n));
+  HIPCHK(h->st_res.ensure(residue_floats + 4));
+  HIPCHK(h->st_pcm.ensure(pcm_n));
+  HIPCHK(h->st_emit.ensure(P));
+  vsyn_taps dt = {nullptr, nullptr, nullptr};
+  if (taps && taps->after_envelope) {
+    HIPCHK(h->st_env.ensure(residue_floats + 4));
+    dt.after_envelope = h->st_env.p;
+  }
+  if (taps && taps->pcm_after_mdct) {
+    HIPCHK(h->st_blk.ensure(2 * residue_floats + 8));
+    dt.pcm_after_mdct = h->st_blk.p;
+  }
+  if (taps && taps->floor_final) {
+    HIPCHK(h->st_fy.ensure(ys_n));
+    dt.floor_final = h->st_fy.p;
+    HIPCHK(hipMemset(h->st_fy.p, 0, ys_n * sizeof(uint16_t)));
+  }
+  HIPCHK(hipMemcpy(h->st_pk.p, packets, sizeof(vsyn_packet) * P, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->st_seg.p, segments, sizeof(vsyn_segment) * S, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->st_ys.p, ys, sizeof(uint16_t) * ys_n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->st_res.p, residue, sizeof(float) * residue_floats, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(h->st_pcm.p, 0, sizeof(float) * pcm_n));
+  if (dt.after_envelope) HIPCHK(hipMemset(dt.after_envelope, 0, sizeof(float) * residue_floats));
+  if (dt.pcm_after_mdct) HIPCHK(hipMemset(dt.pcm_after_mdct, 0, sizeof(float) * 2 * residue_floats));
+  const bool any_tap = dt.after_envelope || dt.pcm_after_mdct || dt.floor_final;
+  int rc = vsyn_submit_device(h, P, h->st_pk.p, S, h->st_seg.p, max_seg, h->st_ys.p, h->st_res.p, h->st_pcm.p, plane_stride,
+                              h->st_emit.p, any_tap ? &dt : nullptr, flags, nullptr, err);
+  if (rc) return rc;
+  vsyn_status st;
+  rc = vsyn_sync_status(h, nullptr, &st, err);
+  if (status) *status = st;
+  if (rc != VSYN_OK && rc != VSYN_ERR_STREAM) return rc;
+  HIPCHK(hipMemcpy(pcm, h->st_pcm.p, sizeof(float) * pcm_n, hipMemcpyDeviceToHost));
+  if (emit_len) HIPCHK(hipMemcpy(emit_len, h->st_emit.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost));
+  if (dt.after_envelope) HIPCHK(hipMemcpy(taps->after_envelope, dt.after_envelope, sizeof(float) * residue_floats, hipMemcpyDeviceToHost));
+  if (dt.pcm_after_mdct) HIPCHK(hipMemcpy(taps->pcm_after_mdct, dt.pcm_after_mdct, sizeof(float) * 2 * residue_floats, hipMemcpyDeviceToHost));
+  if (dt.floor_final) HIPCHK(hipMemcpy(taps->floor_final, dt.floor_final, sizeof(uint16_t) * ys_n, hipMemcpyDeviceToHost));
+  return rc;
+}
+
+int vsyn_imdct_device(vsyn_handle* h, uint32_t n, uint32_t count, const float* d_in, float* d_out, void* hip_stream, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  if (count == 0) return VSYN_OK;
+  if (!d_in || !d_out) return fail(err, VSYN_ERR_INVALID, "NULL pointer");
+  int b;
+  if (n == h->H.bs[1]) b = 1;
+  else if (n == h->H.bs[0]) b = 0;
+  else return fail(err, VSYN_ERR_INVALID, "n=%u is neither blocksize of this handle (%u/%u)", n, h->H.bs[0], h->H.bs[1]);
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  hipError_t e = hipSuccess;
+  bool done = false;
+  HIPCHK(profile_begin(h, s, fused_imdct_kernel_name(n)));
+  e = fused_imdct_launch(h->H, h->d_const, h->fused, b, n, count, d_in, d_out, s, &done);
+  if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "imdct launch failed: %s", hipGetErrorString(e));
+  if (!done) {
+    h->profile_kernel = "vsyn_imdct_plain_kernel";
+    const uint32_t grid = std::min<uint32_t>(count, 256u * 16u);
+    vsyn_imdct_plain_kernel<<<grid, 256, (size_t)n * 4, s>>>(h->d_const, b, n, count, d_in, d_out);
+  }
+  HIPCHK(profile_end(h, s));
+  HIPCHK(hipGetLastError());
+  return VSYN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,485 @@
+// vsyn_staged.h — layout / floor-unwrap kernels (used by every path) and the STAGED synthesis kernels:
+// any blocksize 64..8192, any channel count / coupling list, every intermediate materialised in HBM so it
+// can be handed out as a debug tap (the reference's push_data_* hooks).  Correctness-first; the fused
+// kernels in vsyn_fused.h are the speed path.  Compiled with -ffp-contract=off: every a*b+c below is two
+// roundings unless written as __builtin_fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vsyn_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// K0  layout: one workgroup per segment.  Restates the integer bookkeeping of
+// VorbisStreamDecodeState::advancePcmOffsetBeginAudioPacket / forwardReadyPcm (hpp:1019-1067) as a scan:
+//   natural frames L_q = n_{q-1}/4 + n_q/4 (0 for a stream's first packet, hpp:1021-1027)
+//   abs_after_q = granule_q if granule_q >= 0 (hpp:1028-1044,1056-1057) else abs_before_q + L_q
+// plus the residue offset prefix sum and the nonzero propagate (hpp:1174-1180).
+// ------------------------------------------------------------------------------------------------
+struct AbsScan {
+  int64_t val;
+  int set;
+};
+__device__ __forceinline__ AbsScan abs_combine(AbsScan a, AbsScan b) {
+  AbsScan r;
+  if (b.set) return b;
+  r.set = a.set;
+  r.val = a.val + b.val;
+  return r;
+}
+
+__global__ void __launch_bounds__(256)
+vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet* __restrict__ pk, uint32_t S,
+                   const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
+                   SegInfo* __restrict__ sinfo, StreamState* __restrict__ state, uint32_t* __restrict__ emit_len,
+                   DevStatus* __restrict__ status) {
+  const ConstHeader* H = hdr_of(cb);
+  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  if (g >= S) return;
+  const vsyn_segment sg = segs[g];
+  const bool seg_ok = sg.stream < H->max_streams && (uint64_t)sg.first_packet + sg.num_packets <= P && (sg.residue_off & 3) == 0;
+  if (!seg_ok) {
+    if (t == 0) {
+      raise_status(status, VSYN_ST_BAD_SEGMENT, sg.first_packet < P ? sg.first_packet : 0);
+      sinfo[g] = SegInfo{0, 0, 0, 0};
+    }
+    // mark every packet we may safely touch as bad so later kernels skip it
+    if ((uint64_t)sg.first_packet + sg.num_packets <= P)
+      for (uint32_t q = t; q < sg.num_packets; q += 256) {
+        PktInfo pi = {};
+        pi.bad = 1;
+        pi.n = (uint16_t)H->bs[0];
+        info[sg.first_packet + q] = pi;
+      }
+    return;
+  }
+  const uint32_t C = H->channels, num = sg.num_packets;
+  StreamState st0 = state[sg.stream];
+  const bool reset = (sg.flags & VSYN_SEG_RESET) != 0;
+  const uint32_t carry_n = (!reset && st0.has_prev) ? st0.prev_n : 0;
+  const int64_t abs0 = reset ? 0 : (int64_t)st0.abs_total_pos;
+
+  __shared__ AbsScan s_abs[256];
+  __shared__ uint64_t s_res[256];
+  __shared__ int64_t s_abs_end;
+  __shared__ uint32_t s_last_n;
+
+  const uint32_t per = (num + 255) / 256;
+  const uint32_t qb = min(num, t * per), qe = min(num, qb + per);
+  const vsyn_packet* spk = pk + sg.first_packet;
+
+  auto block_n = [&](uint32_t q) -> uint32_t {
+    uint32_t m = spk[q].mode;
+    return (m < H->num_modes && H->mode_blockflag[m]) ? H->bs[1] : H->bs[0];
+  };
+
+  // pass A: per-thread aggregate
+  AbsScan agg = {0, 0};
+  uint64_t res = 0;
+  {
+    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? block_n(qb - 1) : 0);
+    for (uint32_t q = qb; q < qe; ++q) {
+      uint32_t n = block_n(q);
+      AbsScan e;
+      int64_t gr = spk[q].granule;
+      e.set = gr >= 0;
+      e.val = e.set ? gr : (prev_n ? (int64_t)(prev_n / 4 + n / 4) : 0);
+      agg = abs_combine(agg, e);
+      res += (uint64_t)C * (n / 2);
+      prev_n = n;
+    }
+  }
+  s_abs[t] = agg;
+  s_res[t] = res;
+  __syncthreads();
+  if (t == 0) {  // 256-step serial exclusive scan: negligible next to the synthesis kernels
+    AbsScan run = {0, 0};
+    uint64_t r = 0;
+    for (int i = 0; i < 256; ++i) {
+      AbsScan a = s_abs[i];
+      uint64_t x = s_res[i];
+      s_abs[i] = run;
+      s_res[i] = r;
+      run = abs_combine(run, a);
+      r += x;
+    }
+  }
+  __syncthreads();
+
+  // pass B
+  {
+    AbsScan pre = s_abs[t];
+    int64_t abs_before = pre.set ? pre.val : abs0 + pre.val;
+    uint64_t res_off = sg.residue_off + s_res[t];
+    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? block_n(qb - 1) : 0);
+    for (uint32_t q = qb; q < qe; ++q) {
+      const uint32_t p = sg.first_packet + q;
+      const vsyn_packet k = spk[q];
+      PktInfo pi = {};
+      const bool mode_ok = k.mode < H->num_modes;
+      if (!mode_ok) raise_status(status, VSYN_ST_BAD_MODE, p);
+      const uint32_t lng = mode_ok && H->mode_blockflag[k.mode] ? 1u : 0u;
+      const uint32_t n = H->bs[lng];
+      const uint32_t L = prev_n ? prev_n / 4 + n / 4 : 0;
+      int64_t abs_after = abs_before + L;
+      uint32_t emit = L;
+      bool bad = !mode_ok;
+      if (k.granule >= 0) {
+        // hpp:1029 (position already past the page granule) and hpp:1041 (packets cannot reach it)
+        if (k.granule < abs_before || k.granule > abs_before + (int64_t)L) {
+          raise_status(status, VSYN_ST_GRANULE, p);
+          bad = true;
+          emit = 0;
+        } else {
+          emit = (uint32_t)(k.granule - abs_before);
+        }
+        abs_after = k.granule;
+      }
+      const int64_t rel = abs_before - abs0;
+      if (rel < 0 || (uint64_t)rel + emit > plane_stride) {
+        if (emit) raise_status(status, VSYN_ST_PLANE_OVERFLOW, p);
+        if (emit) bad = true;
+        emit = 0;
+      }
+      pi.res_off = res_off;
+      pi.out_pos = rel < 0 ? 0u : (uint32_t)rel;
+      pi.emit = emit;
+      pi.n = (uint16_t)n;
+      pi.lng = (uint8_t)lng;
+      pi.widx = lng ? (uint8_t)((k.prev_long ? 1 : 0) | (k.next_long ? 2 : 0)) : 0;
+      pi.mapping = mode_ok ? H->mode_mapping[k.mode] : 0;
+      pi.bad = bad ? 1 : 0;
+      const uint32_t chan_mask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
+      uint32_t own = k.floor_used & chan_mask, used = own;
+      const MapConst* mc = map_of(cb, pi.mapping);
+      for (uint32_t i = 0; i < mc->ncoup; ++i) {  // hpp:1175-1180
+        uint32_t m = mc->coup[2 * i], a = mc->coup[2 * i + 1];
+        if (((used >> m) | (used >> a)) & 1u) used |= (1u << m) | (1u << a);
+      }
+      pi.own = own;
+      pi.used = used;
+      info[p] = pi;
+      if (emit_len) emit_len[p] = emit;
+      if (q == num - 1) {
+        s_abs_end = abs_after;
+        s_last_n = n;
+      }
+      abs_before = abs_after;
+      res_off += (uint64_t)C * (n / 2);
+      prev_n = n;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    SegInfo si;
+    si.has_carry = carry_n ? 1u : 0u;
+    si.carry_n = carry_n;
+    si.parity_in = reset ? 0u : st0.parity;
+    if (num == 0) {
+      si.total_emit = 0;
+      sinfo[g] = si;
+      if (reset) state[sg.stream] = StreamState{0, 0, 0, 0, 0};
+      return;
+    }
+    si.total_emit = (uint32_t)(s_abs_end - abs0);
+    sinfo[g] = si;
+    StreamState ns;
+    ns.abs_total_pos = (uint64_t)s_abs_end;
+    ns.has_prev = 1;
+    ns.prev_n = s_last_n;
+    ns.parity = si.parity_in ^ 1u;
+    ns.pad = 0;
+    state[sg.stream] = ns;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  floor-1 step 1 (amplitude value synthesis), hpp:521-559, one thread per (packet, channel).
+// Serial over <=65 posts, parallel over the batch. Neighbour indices come precomputed from the setup
+// (Utils.hpp:60-118 depend on xs only).  uint32 wrap-around semantics as in the reference (y_t = uint32_t).
+// Output row: final_y * multiplier (saturated to 15 bits) | step2_flag << 15, header order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t render_point_u32(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t X) {
+  // Utils.hpp:122-137
+  uint32_t adx = x1 - x0;
+  bool up = y1 >= y0;
+  uint32_t ady = up ? y1 - y0 : y0 - y1;
+  uint32_t off = (ady * (X - x0)) / adx;
+  return up ? y0 + off : y0 - off;
+}
+
+__global__ void __launch_bounds__(256)
+vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info,
+                         const uint16_t* __restrict__ ys, uint16_t* __restrict__ fy_out, DevStatus* __restrict__ status) {
+  const ConstHeader* H = hdr_of(cb);
+  const uint32_t C = H->channels, stride = H->ys_stride;
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= P * C) return;
+  const uint32_t p = gid / C, c = gid % C;
+  const PktInfo pi = info[p];
+  uint16_t* out = fy_out + (size_t)gid * stride;
+  if (pi.bad || !((pi.own >> c) & 1u)) return;
+  const FloorConst* fc = floor_of(cb, map_of(cb, pi.mapping)->chfloor[c]);
+  const uint16_t* row = ys + (size_t)gid * stride;
+  const uint32_t posts = fc->posts, range = fc->range, mult = fc->mult;
+
+  uint32_t fy[VSYN_MAX_POSTS];
+  uint64_t flags_lo = 3;  // posts 0..63
+  uint32_t flag_64 = 0;   // post 64
+  fy[0] = row[0];
+  fy[1] = row[1];
+  bool bad = false;
+  for (uint32_t i = 2; i < posts; ++i) {
+    const uint32_t lo = fc->lo[i], hi = fc->hi[i];
+    const uint32_t predicted = render_point_u32(fc->xs[lo], fy[lo], fc->xs[hi], fy[hi], fc->xs[i]);
+    const uint32_t val = row[i];
+    if (predicted > range) {  // hpp:536
+      bad = true;
+      break;
+    }
+    const uint32_t high_room = range - predicted, low_room = predicted;
+    const uint32_t room = min(high_room, low_room) * 2;
+    uint32_t f;
+    if (val == 0) {
+      f = predicted;
+    } else {
+      flags_lo |= (1ull << lo) | (1ull << hi);  // lo, hi < i <= 64
+      if (i < 64) flags_lo |= 1ull << i; else flag_64 = 1;
+      if (val >= room)
+        f = high_room > low_room ? val - low_room + predicted : predicted - val + high_room - 1;
+      else
+        f = (val & 1u) ? predicted - (val + 1) / 2 : predicted + val / 2;
+    }
+    fy[i] = f;
+  }
+  if (bad) {
+    raise_status(status, VSYN_ST_FLOOR_RANGE, p);
+    for (uint32_t i = 0; i < posts; ++i) out[i] = 0x8000;  // flat zero curve, all flagged: harmless
+    return;
+  }
+  for (uint32_t i = 0; i < posts; ++i) {
+    uint32_t v = fy[i] * mult;  // hpp:573,578
+    if (v > 0x7FFFu || fy[i] > 0x7FFFu) v = 0x7FFFu;  // wrapped / absurd amplitude: renders >= 256 -> FLOOR_VALUE later
+    uint32_t fl = i < 64 ? (uint32_t)((flags_lo >> i) & 1ull) : flag_64;
+    out[i] = (uint16_t)(v | (fl << 15));
+  }
+}
+
+// floor-1 step 2 for ONE bin (hpp:563-589): value of the piecewise-linear integer curve at x.
+// render_line's DDA (Utils.hpp:143-183) equals render_point per x (tests/test_oracle_vs_ref.py::test_render_helpers).
+// Generic linear walk over the sorted posts; the fused kernels use a precomputed segment table instead.
+__device__ __forceinline__ uint32_t floor1_curve_at(const FloorConst* fc, const uint16_t* __restrict__ fyrow, uint32_t x) {
+  uint32_t lx = 0, ly = fyrow[fc->sorted_idx[0]] & 0x7FFFu;
+  for (uint32_t s = 1; s < fc->posts; ++s) {
+    const uint32_t v = fyrow[fc->sorted_idx[s]];
+    if (!(v >> 15)) continue;
+    const uint32_t hx = fc->xs_sorted[s], hy = v & 0x7FFFu;
+    if (x < hx) return render_point_u32(lx, ly, hx, hy, x);
+    lx = hx;
+    ly = hy;
+  }
+  return ly;  // flat extension, hpp:583-584
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 (staged)  inverse coupling (hpp:1213-1241) + floor product (hpp:1243-1255): one thread per bin,
+// all channels of the bin handled by the same thread (couplings chain across channels), in place in `env`.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inverse_couple(float& m, float& a) {  // hpp:1220-1239
+  float m2 = m, a2 = a;
+  if (m > 0.f) {
+    if (a > 0.f) a2 = m - a;
+    else { a2 = m; m2 = m + a; }
+  } else {
+    if (a > 0.f) a2 = m + a;
+    else { a2 = m; m2 = m - a; }
+  }
+  m = m2;
+  a = a2;
+}
+
+__global__ void __launch_bounds__(256)
+vsyn_spectrum_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info,
+                     const float* __restrict__ residue, const uint16_t* __restrict__ fy, float* __restrict__ env,
+                     DevStatus* __restrict__ status) {
+  const ConstHeader* H = hdr_of(cb);
+  const uint32_t p = blockIdx.x;  // grid.x carries the packet index (grid.y/z are limited to 65535)
+  const PktInfo pi = info[p];
+  if (pi.bad) return;
+  const uint32_t n2 = pi.n / 2u, C = H->channels;
+  const uint32_t i = blockIdx.y * 256 + threadIdx.x;
+  if (i >= n2) return;
+  const float* src = residue + pi.res_off;
+  float* dst = env + pi.res_off;
+  for (uint32_t c = 0; c < C; ++c) dst[(size_t)c * n2 + i] = src[(size_t)c * n2 + i];
+  const MapConst* mc = map_of(cb, pi.mapping);
+  for (uint32_t k = mc->ncoup; k > 0; --k) {  // reverse order, hpp:1214
+    const uint32_t m = mc->coup[2 * (k - 1)], a = mc->coup[2 * (k - 1) + 1];
+    float mv = dst[(size_t)m * n2 + i], av = dst[(size_t)a * n2 + i];
+    inverse_couple(mv, av);
+    dst[(size_t)m * n2 + i] = mv;
+    dst[(size_t)a * n2 + i] = av;
+  }
+  const float* invdb = invdb_of(cb);
+  for (uint32_t c = 0; c < C; ++c) {
+    if (!((pi.used >> c) & 1u)) continue;
+    float f = 0.f;  // propagated-but-undecoded floor: floor_outputs stays zero (hpp:1159, 1169)
+    if ((pi.own >> c) & 1u) {
+      const FloorConst* fc = floor_of(cb, mc->chfloor[c]);
+      const uint32_t v = floor1_curve_at(fc, fy + ((size_t)p * C + c) * H->ys_stride, i);
+      if (v >= 256u) {  // hpp:587
+        raise_status(status, VSYN_ST_FLOOR_VALUE, p);
+        f = 0.f;
+      } else {
+        f = invdb[v];
+      }
+    }
+    dst[(size_t)c * n2 + i] *= f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 (staged)  IMDCT for any n = 64..8192: one workgroup per block, radix-2 Stockham FFT of n/4 complex
+// points in LDS.  Computes what mdct_backward (mdct.cpp:433-527) computes, by a different factorisation:
+//   c[k]  = (X[2k] + i X[M-1-2k]) * exp(-i pi (4k+1) / (4M)),  M = n/2, k < n/4
+//   Cf    = FFT_{n/4}(c);  d[m] = Cf[m] * exp(-i pi m / M)
+//   u[2m] = Re d[m], u[M-1-2m] = -Im d[m]                     (u = DCT-IV of X)
+//   y[i]  = u[i+M/2] (i < M/2);  -u[3M/2-1-i] (M/2 <= i < 3M/2);  -u[i-3M/2] (i >= 3M/2)
+// Twiddles are computed in double on the host and stored as f32 (like mdct_init, mdct.cpp:101-110).
+// Results agree with the reference to ~1e-7 * |output| (gate: 1e-5 abs at |pcm| <= 1, compare-debug-out.py:90).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+
+__device__ void imdct_block_lds(const uint8_t* __restrict__ cb, int b, uint32_t n, const float* __restrict__ X,
+                                float* __restrict__ y, float2* bufA, float2* bufB) {
+  const uint32_t M = n / 2, N4 = n / 4, T = blockDim.x, t = threadIdx.x;
+  const float2* pre = pre_of(cb, b);
+  const float2* post = post_of(cb, b);
+  const float2* tw = fft_of(cb, b);
+  for (uint32_t k = t; k < N4; k += T) bufA[k] = cmul(make_float2(X[2 * k], X[M - 1 - 2 * k]), pre[k]);
+  __syncthreads();
+  float2* src = bufA;
+  float2* dst = bufB;
+  for (uint32_t Ns = 1; Ns < N4; Ns <<= 1) {
+    const uint32_t tstride = N4 / (2 * Ns);
+    for (uint32_t j = t; j < N4 / 2; j += T) {
+      const uint32_t k = j & (Ns - 1);
+      const float2 v0 = src[j];
+      const float2 v1 = cmul(src[j + N4 / 2], tw[k * tstride]);
+      const uint32_t o = ((j - k) << 1) + k;
+      dst[o] = make_float2(v0.x + v1.x, v0.y + v1.y);
+      dst[o + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+    }
+    __syncthreads();
+    float2* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  float* u = (float*)dst;  // M floats == N4 float2
+  for (uint32_t m = t; m < N4; m += T) {
+    const float2 d = cmul(src[m], post[m]);
+    u[2 * m] = d.x;
+    u[M - 1 - 2 * m] = -d.y;
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < n; i += T) {
+    float v;
+    if (i < M / 2) v = u[i + M / 2];
+    else if (i < 3 * M / 2) v = -u[3 * M / 2 - 1 - i];
+    else v = -u[i - 3 * M / 2];
+    y[i] = v;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+vsyn_imdct_staged_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info,
+                         const float* __restrict__ env, float* __restrict__ blk) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  const ConstHeader* H = hdr_of(cb);
+  const uint32_t p = blockIdx.x / H->channels, c = blockIdx.x % H->channels;
+  const PktInfo pi = info[p];
+  if (pi.bad) return;
+  const uint32_t n = pi.n;
+  float2* bufA = (float2*)lds_raw;
+  float2* bufB = bufA + n / 4;
+  imdct_block_lds(cb, pi.lng, n, env + pi.res_off + (size_t)c * (n / 2), blk + 2 * pi.res_off + (size_t)c * n, bufA, bufB);
+}
+
+// plain [count][n/2] -> [count][n] (BASELINE config 2), generic version
+__global__ void __launch_bounds__(256)
+vsyn_imdct_plain_kernel(const uint8_t* __restrict__ cb, int b, uint32_t n, uint32_t count, const float* __restrict__ in,
+                        float* __restrict__ out) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  float2* bufA = (float2*)lds_raw;
+  float2* bufB = bufA + n / 4;
+  for (uint32_t blk = blockIdx.x; blk < count; blk += gridDim.x)
+    imdct_block_lds(cb, b, n, in + (size_t)blk * (n / 2), out + (size_t)blk * n, bufA, bufB);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 (staged)  window + overlap-add + PCM hand-off (hpp:1008-1059) as a gather: emitted sample s of packet q
+//   = fl( fl(prev[n_prev/2 + s] * w_prev[n_prev/2 + s]) + fl(cur[j] * w_cur[j]) ),  j = n_cur/2 - L + s,
+// each term present only where its block covers the sample (tests/test_oracle_vs_ref.py pins this against
+// the reference's sliding buffer).  Mul and add are rounded separately, as `buf += pcm*window` is upstream.
+// The last packet of a segment also stores its windowed right half as the stream's carry.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vsyn_overlap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info, uint32_t S,
+                    const vsyn_segment* __restrict__ segs, const SegInfo* __restrict__ sinfo, const uint32_t* __restrict__ seg_of_pkt,
+                    const float* __restrict__ blk, float* __restrict__ pcm, uint64_t plane_stride, float* __restrict__ carry) {
+  const ConstHeader* H = hdr_of(cb);
+  const uint32_t p = blockIdx.x, c = blockIdx.y, C = H->channels;
+  const uint32_t s = blockIdx.z * 256 + threadIdx.x;
+  const uint32_t g = seg_of_pkt[p];
+  if (g == 0xFFFFFFFFu) return;
+  const PktInfo pi = info[p];
+  if (pi.bad) return;
+  const vsyn_segment sg = segs[g];
+  const SegInfo si = sinfo[g];
+  const uint32_t q = p - sg.first_packet, n = pi.n, half1 = H->bs[1] / 2;
+  const float* cur = blk + 2 * pi.res_off + (size_t)c * n;
+  const float* wc = win_of(cb, pi.lng, pi.widx);
+  const size_t carry_half = (size_t)H->max_streams * C * half1;
+
+  // prev block (or carry)
+  uint32_t n_prev = 0;
+  const float* prev = nullptr;
+  const float* wp = nullptr;
+  const float* cin = nullptr;
+  if (q > 0) {
+    const PktInfo pp = info[p - 1];
+    if (!pp.bad) {
+      n_prev = pp.n;
+      prev = blk + 2 * pp.res_off + (size_t)c * n_prev;
+      wp = win_of(cb, pp.lng, pp.widx);
+    }
+  } else if (si.has_carry) {
+    n_prev = si.carry_n;
+    cin = carry + si.parity_in * carry_half + ((size_t)sg.stream * C + c) * half1;
+  }
+  if (s < pi.emit && n_prev) {
+    const uint32_t L = n_prev / 4 + n / 4;
+    float acc = 0.f;
+    const uint32_t ip = n_prev / 2 + s;
+    if (ip < n_prev) acc = acc + (cin ? cin[s] : prev[ip] * wp[ip]);
+    const int32_t j = (int32_t)(n / 2) - (int32_t)L + (int32_t)s;
+    if (j >= 0) acc = acc + cur[j] * wc[j];
+    pcm[((size_t)g * C + c) * plane_stride + pi.out_pos + s] = acc;
+  }
+  if (q == sg.num_packets - 1 && s < n / 2) {
+    float* cout = carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * half1;
+    cout[s] = cur[n / 2 + s] * wc[n / 2 + s];
+  }
+}
+
+// packet -> segment map for the gather kernel (segments are few; packets many)
+__global__ void __launch_bounds__(256)
+vsyn_segmap_kernel(uint32_t P, uint32_t S, const vsyn_segment* __restrict__ segs, uint32_t* __restrict__ seg_of_pkt) {
+  const uint32_t g = blockIdx.y;
+  if (g >= S) return;
+  const vsyn_segment sg = segs[g];
+  if ((uint64_t)sg.first_packet + sg.num_packets > P) return;
+  for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < sg.num_packets; q += gridDim.x * 256) seg_of_pkt[sg.first_packet + q] = g;
+}

@@ -1,0 +1,211 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against (a) the committed dumps of the
+reference decoder and (b) the CPU oracle on seeded synthetic batches.
+Bars: integer/index work (emit_len, unwrapped floor posts) exact; inverse coupling + floor product
+("after_envelope") bit-exact; IMDCT / PCM within 1e-5 absolute at |pcm| <= 1 (compare-debug-out.py:90,
+BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_binding as ob
+from parseoggvorbis_amd import binding
+from parseoggvorbis_amd.binding import SetupSpec
+from tests.workloads import fixture_like_spec, load_golden, synth_batch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+PATHS = [0, binding.VSYN_SUBMIT_STAGED]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def check(got, want, scale_tol=True):
+    assert got["rc"] == want["rc"] == 0, (got["rc"], got["flags"], want["rc"])
+    assert np.array_equal(got["emit_len"], want["emit_len"])
+    scale = max(1.0, float(np.abs(want["pcm"]).max())) if scale_tol else 1.0
+    err = float(np.abs(got["pcm"] - want["pcm"]).max())
+    assert err < TOL * scale, (err, scale)
+    return err
+
+
+@pytest.mark.parametrize("flags", PATHS)
+@pytest.mark.parametrize("name", ["test.stereo44khz", "test.mono44khz"])
+def test_reference_fixture_dumps(name, flags):
+    """Inputs = the reference's own hooks on its .ogg fixtures; outputs vs its 'pcm' hook (max |pcm| 0.58)."""
+    spec, b, z = load_golden(name)
+    gpu = binding.Synth(spec, max_streams=1)
+    total = b["pcm"].shape[1]
+    r = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], total + 8, flags=flags)
+    assert r["rc"] == 0 and r["flags"] == 0
+    assert np.array_equal(r["emit_len"], b["emit_len"])
+    assert int(r["emit_len"].sum()) == total
+    assert np.abs(r["pcm"][0][:, :total] - b["pcm"]).max() < TOL
+    assert not r["pcm"][0][:, total:].any()
+
+
+@pytest.mark.parametrize("name", ["test.stereo44khz", "test.mono44khz"])
+def test_reference_fixture_taps(name):
+    spec, b, z = load_golden(name)
+    gpu = binding.Synth(spec, max_streams=1)
+    total = b["pcm"].shape[1]
+    r = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], total, want_taps=True)
+    assert r["rc"] == 0
+    C = spec.channels
+    n_of = np.where(z["mode"] == 1, spec.blocksize1, spec.blocksize0)
+    off = np.concatenate([[0], np.cumsum(C * n_of // 2)])
+    for k in z["tap_packets"]:
+        n = int(n_of[k])
+        for c in range(C):
+            key = "p%d_c%d_" % (k, c)
+            env = r["taps"]["after_envelope"][off[k] + c * n // 2: off[k] + (c + 1) * n // 2]
+            assert np.array_equal(bits(env), bits(z[key + "env"])), key  # exact: adds/subs and one multiply
+            md = r["taps"]["pcm_after_mdct"][2 * off[k] + c * n: 2 * off[k] + (c + 1) * n]
+            assert np.abs(md - z[key + "mdct"]).max() < TOL, key
+            if key + "final_ys" in z.files:
+                mult, xs = spec.floors[int(z["mode"][k])]
+                row = r["taps"]["floor_final"].reshape(-1, C, gpu.ys_stride)[k, c, :len(xs)]
+                assert np.array_equal(row & 0x7FFF, z[key + "final_ys"] * mult)
+                assert np.array_equal(row >> 15, z[key + "flag"])
+
+
+SHAPES = [  # (channels, bs0, bs1, pattern, streams, packets)
+    (2, 256, 2048, "mixed", 5, 40),
+    (2, 256, 2048, "long", 3, 37),
+    (1, 256, 2048, "short", 2, 50),
+    (1, 64, 64, "long", 2, 9),
+    (2, 64, 8192, "mixed", 2, 14),
+    (3, 128, 1024, "mixed", 3, 21),
+    (2, 512, 512, "short", 2, 8),
+    (2, 2048, 4096, "mixed", 2, 12),
+]
+
+
+@pytest.mark.parametrize("flags", PATHS)
+@pytest.mark.parametrize("C,bs0,bs1,pattern,streams,npk", SHAPES)
+def test_synthetic_vs_oracle(C, bs0, bs1, pattern, streams, npk, flags):
+    spec = fixture_like_spec(C, bs0, bs1)
+    b = synth_batch(spec, streams, npk, pattern, seed=bs0 + bs1 + C, unused_frac=0.1, granule_last=True)
+    want = ob.OracleSynth(spec, streams).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    got = binding.Synth(spec, max_streams=streams).submit_host(b["packets"], b["segments"], b["ys"], b["residue"],
+                                                             b["plane_stride"], flags=flags)
+    check(got, want)
+
+
+def test_many_channels_chained_couplings():
+    """5.1-style mapping: three coupling steps sharing channels (reverse-order application matters)."""
+    C = 6
+    xs_s = [0, 64, 8, 32, 16, 48]
+    xs_l = [0, 512] + [int(v) for v in np.random.default_rng(1).permutation(np.arange(1, 512))[:40]]
+    coup = [(0, 1), (0, 2), (3, 4)]
+    spec = SetupSpec(C, 128, 1024, [(1, xs_s), (3, xs_l)], [(coup, [0] * C), (coup, [1] * C)], [(0, 0), (1, 1)])
+    b = synth_batch(spec, 2, 16, "mixed", seed=11, unused_frac=0.3)
+    want = ob.OracleSynth(spec, 2).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
+    got = binding.Synth(spec, max_streams=2).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
+    check(got, want)
+    assert np.array_equal(bits(got["taps"]["after_envelope"]), bits(want["taps"]["after_envelope"]))
+    assert np.array_equal(got["taps"]["floor_final"], want["taps"]["floor_final"])
+
+
+@pytest.mark.parametrize("flags", PATHS)
+def test_streaming_across_submits(flags):
+    """Overlap carry between batches: cutting a stream into several submits == one submit."""
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, 1, 60, "mixed", seed=3)
+    one = binding.Synth(spec, max_streams=2).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=flags)
+    total = int(one["emit_len"].sum())
+    n_of = np.where(b["packets"]["mode"] == 1, spec.blocksize1, spec.blocksize0)
+    off = np.concatenate([[0], np.cumsum(2 * n_of // 2)])
+    gpu = binding.Synth(spec, max_streams=2)
+    cuts = [0, 1, 2, 13, 14, 40, 60]
+    parts = []
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        seg = b["segments"].copy()
+        seg["stream"], seg["first_packet"], seg["num_packets"], seg["flags"] = 1, 0, e - a, 1 if a == 0 else 0
+        r = gpu.submit_host(b["packets"][a:e], seg, b["ys"][a:e], b["residue"][off[a]:off[e]], b["plane_stride"], flags=flags)
+        assert r["rc"] == 0
+        assert np.array_equal(r["emit_len"], one["emit_len"][a:e])
+        parts.append(r["pcm"][0][:, :int(r["emit_len"].sum())])
+    assert np.array_equal(np.concatenate(parts, axis=1), one["pcm"][0][:, :total])  # same kernels, same bits
+
+
+def test_empty_and_ragged_batches():
+    spec = fixture_like_spec(2)
+    gpu = binding.Synth(spec, max_streams=4)
+    orc = ob.OracleSynth(spec, 4)
+    # ragged: segments of very different lengths, one of a single packet, one empty
+    bs = [synth_batch(spec, 1, k, "mixed", seed=k) for k in (1, 2, 31)]
+    pk = np.concatenate([x["packets"] for x in bs])
+    ys = np.concatenate([x["ys"] for x in bs])
+    res = np.concatenate([x["residue"] for x in bs])
+    seg = np.zeros(4, binding.SEGMENT_DTYPE)
+    first, roff = 0, 0
+    for i, x in enumerate(bs):
+        seg[i] = (i, first, len(x["packets"]), 1, roff)
+        first += len(x["packets"])
+        roff += x["residue"].size
+    seg[3] = (3, 0, 0, 1, 0)  # empty segment
+    plane = bs[2]["plane_stride"]
+    for flags in PATHS:
+        gpu.reset()
+        check(gpu.submit_host(pk, seg, ys, res, plane, flags=flags), orc.submit_host(pk, seg, ys, res, plane))
+    # empty batch is a no-op
+    r = gpu.submit_host(pk[:0], seg[:0], ys[:0], res[:0], 16)
+    assert r["rc"] == 0
+
+
+def test_error_flags_match_oracle():
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, 2, 6, "mixed", seed=5)
+    gpu = binding.Synth(spec, max_streams=2)
+    orc = ob.OracleSynth(spec, 2)
+    bad = b["packets"].copy()
+    bad["granule"][4] = 10 ** 9
+    for flags in PATHS:
+        r = gpu.submit_host(bad, b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=flags)
+        w = orc.submit_host(bad, b["segments"], b["ys"], b["residue"], b["plane_stride"])
+        assert r["rc"] == w["rc"] == 4 and r["flags"] & 4 and r["first_bad"] == w["first_bad"] == 4
+    ys = b["ys"].copy()
+    ys[7, 0, 2:] = 255
+    pk = b["packets"].copy()
+    pk["floor_used"][7] |= 1
+    for flags in PATHS:
+        r = gpu.submit_host(pk, b["segments"], ys, b["residue"], b["plane_stride"], flags=flags)
+        w = orc.submit_host(pk, b["segments"], ys, b["residue"], b["plane_stride"])
+        assert r["rc"] == w["rc"] == 4 and (r["flags"] & 3) and r["first_bad"] == w["first_bad"] == 7
+    r = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], 100)
+    assert r["flags"] & 8
+    badmode = b["packets"].copy()
+    badmode["mode"][3] = 9
+    r = gpu.submit_host(badmode, b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert r["flags"] & 16 and r["first_bad"] == 3
+    # after errors the handle is still usable
+    gpu.reset()
+    check(gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"]),
+          orc.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"]))
+
+
+@pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_imdct_only(n):
+    """BASELINE config 2 shape (n=256: 4096 mono packets, sigma=0.05) and every other blocksize."""
+    import torch
+    count = 4096 if n == 256 else 257
+    rng = np.random.default_rng(1234)
+    x = (rng.standard_normal((count, n // 2)) * 0.05 * np.sqrt(128.0 / (n // 2))).astype(np.float32)
+    spec = fixture_like_spec(1, min(n, 256) if n != 64 else 64, max(n, 256) if n != 64 else 64)
+    if n not in (spec.blocksize0, spec.blocksize1):
+        spec = fixture_like_spec(1, n, n)
+    gpu = binding.Synth(spec, max_streams=1)
+    din = torch.from_numpy(x).cuda()
+    dout = torch.zeros((count, n), dtype=torch.float32, device="cuda")
+    gpu.imdct_device(n, count, din.data_ptr(), dout.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dout.cpu().numpy()
+    want = ob.imdct(n, x)
+    assert np.abs(want).max() < 2.0
+    assert np.abs(got - want).max() < TOL
+    # analytic oracle on a few rows (double-precision closed form)
+    cf = np.empty(n, np.float64)
+    for r in (0, count - 1):
+        ob.oracle().orc_imdct_closed_form(n, ob.p(x[r]), ob.p(cf))
+        assert np.abs(got[r] - cf).max() < TOL

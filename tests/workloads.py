@@ -90,7 +90,7 @@ def _encode_ys(xs, mult, target, rng, zero_frac):
     return ys
 
 
-def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, ylo=40, yhi=100, unused_frac=0.0,
+def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, ylo=28, yhi=88, unused_frac=0.0,
                 granule_last=False):
     """Synthetic batch in the shape of BASELINE configs 3/4:
     residue = round(Laplace(b=1.5)) with 60 % zeros; floor amplitudes a random walk in [ylo,yhi] (step +-6)
@@ -148,6 +148,7 @@ def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, yl
             fl = flags1 if pattern != "mixed" else np.roll(flags1, s % 11)
             sizes = np.where(fl, spec.blocksize1, spec.blocksize0)
             total = int(sum(sizes[i - 1] // 4 + sizes[i] // 4 for i in range(1, packets_per_stream)))
-            pk[s * packets_per_stream + packets_per_stream - 1]["granule"] = max(0, total - 37)
+            last_l = int(sizes[-2] // 4 + sizes[-1] // 4) if packets_per_stream > 1 else 0
+            pk[s * packets_per_stream + packets_per_stream - 1]["granule"] = total - min(37, last_l // 2)  # clipped last packet
     plane = packets_per_stream * (spec.blocksize1 // 2) + 64
     return dict(packets=pk, segments=seg, ys=ys, residue=np.concatenate(res_parts), plane_stride=plane)
