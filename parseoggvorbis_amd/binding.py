@@ -120,6 +120,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64: when torch shares the process it must be the HIP runtime that
+        # gets loaded (two runtimes in one process cannot both own the GPU). Plumbing only; torch is optional.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("HIP extension missing: %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % LIB_PATH)

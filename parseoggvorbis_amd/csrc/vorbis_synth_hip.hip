@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "vsyn_device.h"
 #include "vsyn_staged.h"
 #include "vsyn_fused.h"
@@ -91,7 +93,11 @@ struct vsyn_handle {
   float* d_carry = nullptr;
   DevStatus* d_status = nullptr;
   FusedTables fused{};
+  bool fused_ok = false;
+  int num_cus = 256;
   // workspace
+  DevBuf<uint32_t> ws_list;   // staged work list (+ its counter in slot 0 of ws_count)
+  DevBuf<uint32_t> ws_count;
   DevBuf<PktInfo> ws_info;
   DevBuf<SegInfo> ws_seg;
   DevBuf<uint32_t> ws_segmap;
@@ -313,6 +319,8 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   HC(hipMalloc((void**)&h->d_status, sizeof(DevStatus)));
   DevStatus init = {0u, 0xFFFFFFFFu};
   HC(hipMemcpy(h->d_status, &init, sizeof(init), hipMemcpyHostToDevice));
+  h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  h->fused_ok = fused_setup_ok(h->H, h->host_const.data());
   if ((e = fused_tables_create(h->H, h->host_const.data(), &h->fused)) != hipSuccess) {
     fail(err, VSYN_ERR_HIP, "fused table upload failed: %s", hipGetErrorString(e));
     return cleanup(VSYN_ERR_HIP);
@@ -331,6 +339,7 @@ void vsyn_destroy(vsyn_handle* h) {
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_carry) (void)hipFree(h->d_carry);
   if (h->d_status) (void)hipFree(h->d_status);
+  h->ws_list.release(); h->ws_count.release();
   h->ws_info.release(); h->ws_seg.release(); h->ws_segmap.release(); h->ws_fy.release(); h->ws_env.release(); h->ws_blk.release();
   h->st_pk.release(); h->st_seg.release(); h->st_ys.release(); h->st_fy.release(); h->st_res.release(); h->st_pcm.release();
   h->st_env.release(); h->st_blk.release(); h->st_emit.release();
@@ -428,48 +437,71 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   const ConstHeader& H = h->H;
   const uint32_t C = H.channels;
   const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct);
-  const bool staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !fused_supported(H);
+  const bool force_staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !h->fused_ok;
+  const uint32_t R = force_staged ? std::min<uint32_t>(max_seg_packets, 1024u)
+                                  : fused_pick_run_len(h->fused, S, max_seg_packets, h->num_cus);
 
   HIPCHK(h->ws_info.ensure(P));
   HIPCHK(h->ws_seg.ensure(S));
+  HIPCHK(h->ws_segmap.ensure(P));
+  HIPCHK(h->ws_list.ensure(2 * (size_t)P + 64));
+  HIPCHK(h->ws_count.ensure(4));
   uint16_t* fy = taps && taps->floor_final ? taps->floor_final : nullptr;
   if (!fy) {
     HIPCHK(h->ws_fy.ensure((size_t)P * C * H.ys_stride));
     fy = h->ws_fy.p;
   }
 
+  HIPCHK(hipMemsetAsync(h->ws_count.p, 0, sizeof(uint32_t) * 4, s));
   vsyn_layout_kernel<<<S, 256, 0, s>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, h->ws_info.p, h->ws_seg.p,
-                                       h->d_state, d_emit_len, h->d_status);
+                                       h->d_state, d_emit_len, h->d_status, R, force_staged ? 0u : 1u, h->ws_list.p,
+                                       h->ws_count.p, h->ws_segmap.p);
   vsyn_floor_unwrap_kernel<<<(P * C + 255) / 256, 256, 0, s>>>(h->d_const, P, h->ws_info.p, d_ys, fy, h->d_status);
 
-  if (!staged) {
+  if (!force_staged) {
+    FusedArgs a;
+    a.cb = h->d_const;
+    a.binseg = h->fused.d_binseg;
+    a.packets = d_packets;
+    a.segs = d_segments;
+    a.info = h->ws_info.p;
+    a.sinfo = h->ws_seg.p;
+    a.residue = d_residue;
+    a.fy = fy;
+    a.pcm = d_pcm;
+    a.carry = h->d_carry;
+    a.status = h->d_status;
+    a.plane_stride = plane_stride;
+    a.S = S;
+    a.R = R;
+    a.fused_ok = 1;
     HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
-    hipError_t e = fused_launch(h->H, h->d_const, h->fused, P, S, d_segments, max_seg_packets, h->ws_info.p, h->ws_seg.p, d_residue, fy,
-                                d_pcm, plane_stride, h->d_carry, h->d_status, s);
+    hipError_t e = fused_launch(H, a, max_seg_packets, s);
     if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
     HIPCHK(profile_end(h, s));
-  } else {
+  }
+  {
+    // staged kernels walk the work list the layout kernel built (everything when forced, otherwise only the runs
+    // the fused kernel declines: short / mixed blocks); with an empty list they exit at once
     const size_t bound = (size_t)P * C * (H.bs[1] / 2);  // residue floats upper bound (device-resident descriptors)
     float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
     float* blk = taps && taps->pcm_after_mdct ? taps->pcm_after_mdct : nullptr;
     if (!env) {
-      HIPCHK(h->ws_env.ensure(bound));
+      HIPCHK(h->ws_env.ensure(force_staged ? bound : std::min(bound, h->ws_env.cap ? h->ws_env.cap : bound)));
       env = h->ws_env.p;
     }
     if (!blk) {
-      HIPCHK(h->ws_blk.ensure(2 * bound));
+      HIPCHK(h->ws_blk.ensure(force_staged ? 2 * bound : std::min(2 * bound, h->ws_blk.cap ? h->ws_blk.cap : 2 * bound)));
       blk = h->ws_blk.p;
     }
-    HIPCHK(h->ws_segmap.ensure(P));
-    HIPCHK(hipMemsetAsync(h->ws_segmap.p, 0xFF, sizeof(uint32_t) * P, s));
-    vsyn_segmap_kernel<<<dim3(std::min<uint32_t>(64u, (max_seg_packets + 255) / 256), S), 256, 0, s>>>(P, S, d_segments, h->ws_segmap.p);
-    const uint32_t half1 = H.bs[1] / 2;
-    vsyn_spectrum_kernel<<<dim3(P, (half1 + 255) / 256), 256, 0, s>>>(h->d_const, P, h->ws_info.p, d_residue, fy, env, h->d_status);
-    HIPCHK(profile_begin(h, s, "vsyn_imdct_staged_kernel"));
-    vsyn_imdct_staged_kernel<<<P * C, 256, (size_t)H.bs[1] * 4, s>>>(h->d_const, P, h->ws_info.p, env, blk);
-    HIPCHK(profile_end(h, s));
-    vsyn_overlap_kernel<<<dim3(P, C, (half1 + 255) / 256), 256, 0, s>>>(h->d_const, P, h->ws_info.p, S, d_segments, h->ws_seg.p,
-                                                                         h->ws_segmap.p, blk, d_pcm, plane_stride, h->d_carry);
+    const uint32_t grid = force_staged ? std::min<uint32_t>(P * C, 256u * 32u) : 1024u;
+    vsyn_spectrum_kernel<<<std::min<uint32_t>(grid, P), 256, 0, s>>>(h->d_const, h->ws_list.p, h->ws_count.p, h->ws_info.p, d_residue, fy,
+                                                                   env, h->d_status);
+    if (force_staged) HIPCHK(profile_begin(h, s, "vsyn_imdct_staged_kernel"));
+    vsyn_imdct_staged_kernel<<<grid, 256, (size_t)H.bs[1] * 4, s>>>(h->d_const, h->ws_list.p, h->ws_count.p, h->ws_info.p, env, blk);
+    if (force_staged) HIPCHK(profile_end(h, s));
+    vsyn_overlap_kernel<<<grid, 256, 0, s>>>(h->d_const, h->ws_list.p, h->ws_count.p, h->ws_info.p, d_segments, h->ws_seg.p,
+                                             h->ws_segmap.p, blk, d_pcm, plane_stride, h->d_carry);
   }
   HIPCHK(hipGetLastError());
   return VSYN_OK;

@@ -1,24 +1,431 @@
-// vsyn_fused.h — fused single-pass synthesis kernels (speed path).  Placeholder until the wave-level
-// kernels land: reports "unsupported" so every submit takes the staged kernels.
+// vsyn_fused.h — the speed path: ONE kernel from coded floor posts + residue to PCM for runs of long blocks
+// (n = 2048, <= 2 channels), one WAVEFRONT per run of consecutive packets of a stream.
+//
+//   * residue is read once (coalesced 8-byte loads, 512 B per wave-instruction) and PCM is written once
+//     (coalesced 8-byte stores): no intermediate ever touches HBM.
+//   * per lane: 8 complex points per channel.  Point k = lane + 64 t  (t = 0..7) is built from bins 2k and
+//     1023-2k; the second comes from the mirror lane (63 - lane) by one ds_bpermute.
+//   * FFT-512 = three in-lane radix-8 DIF passes; the two index exchanges between them go through a
+//     wave-private, bank-conflict-free padded LDS image (no barriers: a wave's LDS ops execute in order).
+//     Twiddles (pre/post rotation, W512) are staged once per workgroup in LDS.  No MFMA: this is a butterfly
+//     network on f32, not a contraction.
+//   * after the post rotation lane `l` holds points m = kappa + 64 c' (kappa = swap3(l)), and
+//     point m of consecutive packets produces the SAME output samples (s, 1023-s): the overlap carry is
+//     kept in 8 registers per channel for the whole run; the window is applied on the fly.
+//   * the first packet of a run whose predecessor belongs to another wave is recomputed (one-packet halo,
+//     1/R extra work) instead of communicated.
+//
+// Everything the reference rounds separately is rounded separately here (file is built -ffp-contract=off;
+// FMAs are explicit): coupling and floor product are bit-exact, `pcm += block*window` is mul-then-add.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "vsyn_device.h"
 
+#define FUSED_WAVES 4     // waves per workgroup (tables are shared per workgroup)
+#define FUSED_XSLOTS 576  // float2 slots of the per-wave exchange image: 8 rows x 72 (>= 8 x 65)
+
 struct FusedTables {
-  void* d_tables = nullptr;
+  uint8_t* d_binseg = nullptr;  // [num_floors][bs1/2]: sorted-post interval containing bin x
+  int waves_per_cu = 16;
 };
 
-static inline hipError_t fused_tables_create(const ConstHeader&, const uint8_t*, FusedTables*) { return hipSuccess; }
-static inline void fused_tables_destroy(FusedTables*) {}
-static inline bool fused_supported(const ConstHeader&) { return false; }
-static inline const char* fused_kernel_name(const ConstHeader&) { return "none"; }
-static inline const char* fused_imdct_kernel_name(uint32_t) { return "vsyn_imdct_plain_kernel"; }
-static inline hipError_t fused_launch(const ConstHeader&, const uint8_t*, const FusedTables&, uint32_t, uint32_t, const vsyn_segment*,
-                                      uint32_t, const PktInfo*, const SegInfo*, const float*, const uint16_t*, float*, uint64_t,
-                                      float*, DevStatus*, hipStream_t) {
-  return hipErrorNotSupported;
+struct FusedArgs {
+  const uint8_t* cb;
+  const uint8_t* binseg;
+  const vsyn_packet* packets;
+  const vsyn_segment* segs;
+  const PktInfo* info;
+  const SegInfo* sinfo;
+  const float* residue;
+  const uint16_t* fy;
+  float* pcm;
+  float* carry;
+  DevStatus* status;
+  uint64_t plane_stride;
+  uint32_t S, R, fused_ok;
+};
+
+__device__ __forceinline__ float2 f2(float x, float y) { return make_float2(x, y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return f2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return f2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+  return f2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
 }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return f2(a.y, -a.x); }  // * (-i)
+
+// forward DFT-8, natural-order output, in place (decimation in frequency)
+__device__ __forceinline__ void dft8(float2 (&x)[8]) {
+  const float h = 0.70710678118654752440f;
+  float2 a0 = cadd(x[0], x[4]), a1 = cadd(x[1], x[5]), a2 = cadd(x[2], x[6]), a3 = cadd(x[3], x[7]);
+  float2 b0 = csub(x[0], x[4]), b1 = csub(x[1], x[5]), b2 = csub(x[2], x[6]), b3 = csub(x[3], x[7]);
+  b1 = f2((b1.x + b1.y) * h, (b1.y - b1.x) * h);   // * (1 - i)/sqrt2
+  b2 = mul_mi(b2);                                 // * (-i)
+  b3 = f2((b3.y - b3.x) * h, -(b3.x + b3.y) * h);  // * (-1 - i)/sqrt2
+  float2 c0 = cadd(a0, a2), c1 = csub(a0, a2), c2 = cadd(a1, a3), c3 = mul_mi(csub(a1, a3));
+  x[0] = cadd(c0, c2);
+  x[4] = csub(c0, c2);
+  x[2] = cadd(c1, c3);
+  x[6] = csub(c1, c3);
+  float2 d0 = cadd(b0, b2), d1 = csub(b0, b2), d2 = cadd(b1, b3), d3 = mul_mi(csub(b1, b3));
+  x[1] = cadd(d0, d2);
+  x[5] = csub(d0, d2);
+  x[3] = cadd(d1, d3);
+  x[7] = csub(d1, d3);
+}
+
+// FFT-512 across one wave: in: lane l holds z[t] = point l + 64 t; out: lane l holds Z[c'] = bin swap3(l) + 64 c'.
+// xb = this wave's exchange image (FUSED_XSLOTS float2), w = W512^j table (LDS).
+__device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__ xb, const float2* __restrict__ w, uint32_t lane) {
+  const uint32_t c = lane & 7u, hi = lane >> 3;
+  dft8(z);  // over t -> t'
+#pragma unroll
+  for (int t = 1; t < 8; ++t) z[t] = cmulf(z[t], w[lane * t]);
+  // exchange 1: element (t', a, c): lane 8a+c reg t'  ->  lane 8t'+c reg a.   row stride 72: conflict-free both ways
+#pragma unroll
+  for (int t = 0; t < 8; ++t) xb[t * 72 + lane] = z[t];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) z[a] = xb[hi * 72 + a * 8 + c];
+  dft8(z);  // over a -> a'
+#pragma unroll
+  for (int a = 1; a < 8; ++a) z[a] = cmulf(z[a], w[8 * c * a]);  // W64^(c a')
+  // exchange 2: element (h, a', c): lane 8h+c reg a'  ->  lane 8h+a' reg c.   row stride 65
+#pragma unroll
+  for (int a = 0; a < 8; ++a) xb[a * 65 + lane] = z[a];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = xb[c * 65 + hi * 8 + k];
+  dft8(z);  // over c -> c'
+}
+
+__device__ __forceinline__ void couple2(float& m, float& a) {  // hpp:1220-1239
+  float m2 = m, a2 = a;
+  if (m > 0.f) {
+    if (a > 0.f) a2 = m - a;
+    else { a2 = m; m2 = m + a; }
+  } else {
+    if (a > 0.f) a2 = m + a;
+    else { a2 = m; m2 = m - a; }
+  }
+  m = m2;
+  a = a2;
+}
+
+template <int C>
+__global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(const FusedArgs A) {
+  constexpr uint32_t M = 1024, N4 = 512;
+  __shared__ float2 s_pre[N4], s_post[N4], s_w[N4];
+  __shared__ float s_win[2][M];  // left half of the long window for prev flag = 0 / 1; the right half for
+                                 // next flag = f is its mirror image (hpp:850-859 build both from one formula)
+  __shared__ float s_invdb[256];
+  __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
+  __shared__ float4 s_seg[FUSED_WAVES][C][64];
+
+  const uint8_t* __restrict__ cb = A.cb;
+  const ConstHeader* H = hdr_of(cb);
+  {
+    const float2* pre = pre_of(cb, 1);
+    const float2* post = post_of(cb, 1);
+    const float2* tw = fft_of(cb, 1);
+    const float* w0 = win_of(cb, 1, 0);  // prev = short
+    const float* w1 = win_of(cb, 1, 1);  // prev = long
+    const float* idb = invdb_of(cb);
+    for (uint32_t i = threadIdx.x; i < N4; i += FUSED_WAVES * 64) {
+      s_pre[i] = pre[i];
+      s_post[i] = post[i];
+      s_w[i] = tw[i];
+    }
+    for (uint32_t i = threadIdx.x; i < M; i += FUSED_WAVES * 64) {
+      s_win[0][i] = w0[i];
+      s_win[1][i] = w1[i];
+    }
+    for (uint32_t i = threadIdx.x; i < 256; i += FUSED_WAVES * 64) s_invdb[i] = idb[i];
+  }
+  __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
+
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = blockIdx.y;
+  if (g >= A.S) return;
+  const vsyn_segment sg = A.segs[g];
+  const uint32_t run = blockIdx.x * FUSED_WAVES + wave;
+  const uint32_t num = sg.num_packets;
+  const uint32_t qa = run * A.R;
+  if (qa >= num) return;
+  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // the layout kernel flagged it
+  const uint32_t qb = min(num, qa + A.R);
+  const SegInfo si = A.sinfo[g];
+  const vsyn_packet* spk = A.packets + sg.first_packet;
+  if (!run_is_fast(H, spk, qa, qb, si.has_carry ? si.carry_n : 0u, A.fused_ok)) return;  // staged list has it
+
+  const size_t carry_half = (size_t)H->max_streams * C * M;
+
+  float P[C][8];  // overlap carry of the run: -u_prev[511 - s] per point, unwindowed
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[c][k] = 0.f;
+  bool have_prev = false;
+  uint32_t prev_next_long = 1;
+
+  uint32_t bseg[C][4];
+  int bseg_floor[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    bseg_floor[c] = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bseg[c][j] = 0;
+  }
+
+  uint32_t lane_v = lane;
+  for (uint32_t q = qa ? qa - 1 : 0; q < qb; ++q) {
+    // launder the lane id once per packet: keeps the ~40 lane-derived LDS/global addresses from being hoisted
+    // out of the loop and pinned in VGPRs for its whole duration (recomputing them costs a few VALU ops)
+    asm volatile("" : "+v"(lane_v));
+    const uint32_t lane = lane_v;
+    const uint32_t kappa = ((lane & 7u) << 3) | (lane >> 3);
+    float2* xb = s_x[wave];
+    const uint32_t p = sg.first_packet + q;
+    const PktInfo pi = A.info[p];
+    const bool halo = q < qa;
+    const MapConst* mc = map_of(cb, pi.mapping);
+
+    // ---- residue: r[c][t] = bins (2k, 2k+1), k = lane + 64 t -------------------------------------------
+    float2 r[C][8];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) r[c][t] = src[lane + 64 * t];
+    }
+
+    // ---- floor-1 step 2 set-up: one table entry per sorted-post interval (hpp:563-584) ---------------------
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (!((pi.own >> c) & 1u)) continue;
+      const uint32_t f = mc->chfloor[c];
+      const FloorConst* fc = floor_of(cb, f);
+      if (bseg_floor[c] != (int)f) {  // wave-uniform, changes only when the mapping changes
+        const uint8_t* bs = A.binseg + (size_t)f * M;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));
+          if (t & 1) bseg[c][t >> 1] |= two << 16; else bseg[c][t >> 1] = two;
+        }
+        bseg_floor[c] = (int)f;
+      }
+      const uint32_t posts = fc->posts;
+      const uint16_t* row = A.fy + ((size_t)p * C + c) * H->ys_stride;
+      uint32_t v = 0, xs = 0;
+      if (lane < posts) {
+        v = row[fc->sorted_idx[lane]];
+        xs = fc->xs_sorted[lane];
+      }
+      const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
+      const uint64_t below = mask & ((2ull << lane) - 1ull);  // flagged positions <= lane (bit 0 always set)
+      const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
+      const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
+      const bool has_hi = above != 0ull;
+      const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
+      const uint32_t packed = (xs << 16) | (v & 0x7FFFu);
+      const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
+      const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
+      const float x0 = (float)(plo >> 16), y0 = (float)(plo & 0xFFFFu);
+      const float x1 = (float)(phi >> 16), y1 = (float)(phi & 0xFFFFu);
+      float4 e;
+      e.x = x0;
+      e.y = y0;
+      e.z = has_hi ? y1 - y0 : 0.f;
+      e.w = has_hi ? 1.0f / (x1 - x0) : 0.f;
+      s_seg[wave][c][lane] = e;
+    }
+
+    // ---- inverse coupling (hpp:1213-1241): at most one (magnitude, angle) step in this kernel ----------------
+    if (C == 2 && mc->ncoup) {
+      const bool swap = mc->coup[0] != 0;  // magnitude channel is 1
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (!swap) {
+          couple2(r[0][t].x, r[C - 1][t].x);
+          couple2(r[0][t].y, r[C - 1][t].y);
+        } else {
+          couple2(r[C - 1][t].x, r[0][t].x);
+          couple2(r[C - 1][t].y, r[0][t].y);
+        }
+      }
+    }
+
+    const uint32_t emit = halo ? 0u : pi.emit;
+    const float* TL = s_win[pi.widx & 1u];       // this block's left-half window
+    const float* TR = s_win[prev_next_long];     // previous block's right-half window, mirrored
+    const uint32_t cur_next_long = (pi.widx >> 1) & 1u;
+    bool floor_bad = false;
+
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      // ---- floor curve at this lane's 16 bins + product (hpp:585-589, 1243-1255) ---------------------------
+      if ((pi.used >> c) & 1u) {
+        if (!((pi.own >> c) & 1u)) {  // propagated from the coupled channel: floor_outputs is all zero
+#pragma unroll
+          for (int t = 0; t < 8; ++t) r[c][t] = f2(r[c][t].x * 0.f, r[c][t].y * 0.f);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            float fl2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int b = 2 * t + e;
+              const uint32_t sidx = (bseg[c][b >> 2] >> (8 * (b & 3))) & 0xFFu;
+              const float4 sgm = s_seg[wave][c][sidx];
+              const float xf = (float)(2u * (lane + 64u * t) + e);
+              const float err = fabsf(sgm.z) * (xf - sgm.x);                     // exact: < 2^24
+              const float qf = floorf(__builtin_fmaf(err, sgm.w, 0.5f * sgm.w));  // == (ady*dx)/adx, see DESIGN.md
+              const float y = sgm.y + copysignf(qf, sgm.z);
+              floor_bad |= !(y >= 0.f && y < 256.f);  // hpp:587
+              fl2[e] = s_invdb[(uint32_t)fminf(fmaxf(y, 0.f), 255.f)];
+            }
+            r[c][t] = f2(r[c][t].x * fl2[0], r[c][t].y * fl2[1]);
+            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep the LDS gathers from being hoisted en bloc
+          }
+        }
+      }
+
+      // ---- IMDCT: mirror exchange, pre-rotation, FFT-512, post-rotation -----------------------------------
+      float2 z[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float im = __shfl(r[c][7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
+        z[t] = cmulf(f2(r[c][t].x, im), s_pre[lane + 64 * t]);
+      }
+      fft512_wave(z, xb, s_w, lane);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], s_post[kappa + 64 * k]);
+
+      // ---- window + overlap-add + PCM store (hpp:1008-1059) ------------------------------------------------
+      // point m = kappa + 64k gives samples s and 1023-s of this packet's output:
+      //   out[s]      = fl(P*wr(s))      + fl( cc*wl(s))        cc =  u_cur[512+s]
+      //   out[1023-s] = fl(P*wr(1023-s)) + fl(-cc*wl(1023-s))   P  = -u_prev[511-s]
+      float o_s[8], o_m[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t m = kappa + 64u * k;
+        const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
+        const float cc = k >= 4 ? z[k].x : -z[k].y;
+        const float pn = k >= 4 ? z[k].y : -z[k].x;
+        if (emit) {
+          const float wl_s = TL[s], wl_m = TL[1023u - s];
+          float tp_s = 0.f, tp_m = 0.f;
+          if (have_prev) {
+            tp_s = P[c][k] * TR[1023u - s];
+            tp_m = P[c][k] * TR[s];
+          }
+          o_s[k] = tp_s + cc * wl_s;
+          o_m[k] = tp_m + (-cc) * wl_m;
+        }
+        P[c][k] = pn;
+      }
+      if (emit) {
+        float* out = A.pcm + ((size_t)g * C + c) * A.plane_stride + pi.out_pos;
+        const bool fast_store = emit == M && (((uintptr_t)out & 7u) == 0);
+#pragma unroll
+        for (int k = 4; k < 8; ++k) {
+          // partner point 511 - m sits in the mirror lane, slot 7-k, and yields samples s+1 and 1022-s
+          const float n_s = __shfl(o_s[7 - k], 63 - (int)lane);
+          const float n_m = __shfl(o_m[7 - k], 63 - (int)lane);
+          const uint32_t s = 2u * (kappa + 64u * k) - 512u;
+          if (fast_store) {
+            *(float2*)(out + s) = f2(o_s[k], n_s);
+            *(float2*)(out + 1022u - s) = f2(n_m, o_m[k]);
+          } else {
+            if (s < emit) out[s] = o_s[k];
+            if (s + 1u < emit) out[s + 1u] = n_s;
+            if (1022u - s < emit) out[1022u - s] = n_m;
+            if (1023u - s < emit) out[1023u - s] = o_m[k];
+          }
+        }
+      }
+      if (q == num - 1) {  // stream carry for the next submit: windowed right half, natural order
+        float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * M;
+        const float* TN = s_win[cur_next_long];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t m = kappa + 64u * k;
+          const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
+          cout[s] = P[c][k] * TN[1023u - s];
+          cout[1023u - s] = P[c][k] * TN[s];
+        }
+      }
+    }
+    if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
+    have_prev = true;
+    prev_next_long = cur_next_long;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline bool fused_supported(const ConstHeader& H) {
+  return H.bs[1] == 2048 && H.bs[0] <= 2048 && H.channels <= 2;
+}
+
+static inline bool fused_setup_ok(const ConstHeader& H, const uint8_t* host_const) {
+  if (!fused_supported(H)) return false;
+  const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
+  for (uint32_t f = 0; f < H.num_floors; ++f)
+    if (fl[f].posts > 64) return false;  // one ballot covers the sorted posts
+  const MapConst* mp = (const MapConst*)(host_const + H.off_map);
+  for (uint32_t m = 0; m < H.num_mappings; ++m)
+    if (mp[m].ncoup > 1) return false;
+  return true;
+}
+
+static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t* host_const, FusedTables* ft) {
+  const uint32_t half = H.bs[1] / 2;
+  std::vector<uint8_t> tab((size_t)H.num_floors * half);
+  const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
+  for (uint32_t f = 0; f < H.num_floors; ++f) {
+    uint32_t s = 0;
+    for (uint32_t x = 0; x < half; ++x) {
+      while (s + 1 < fl[f].posts && fl[f].xs_sorted[s + 1] <= x) ++s;
+      tab[(size_t)f * half + x] = (uint8_t)s;
+    }
+  }
+  hipError_t e = hipMalloc((void**)&ft->d_binseg, tab.size());
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(ft->d_binseg, tab.data(), tab.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return e;
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vsyn_fused_long_kernel<2>, FUSED_WAVES * 64, 0) == hipSuccess && blocks > 0)
+    ft->waves_per_cu = blocks * FUSED_WAVES;
+  return hipSuccess;
+}
+
+static inline void fused_tables_destroy(FusedTables* ft) {
+  if (ft->d_binseg) (void)hipFree(ft->d_binseg);
+  ft->d_binseg = nullptr;
+}
+
+static inline const char* fused_kernel_name(const ConstHeader&) { return "vsyn_fused_long_kernel"; }
+static inline const char* fused_imdct_kernel_name(uint32_t) { return "vsyn_imdct_plain_kernel"; }
+
+// run length: as few runs as fill the chip once (halo overhead is 1/R), never below 4
+static inline uint32_t fused_pick_run_len(const FusedTables& ft, uint32_t S, uint32_t max_seg_packets, int num_cus) {
+  const char* env = getenv("VSYN_RUN_LEN");
+  if (env && atoi(env) > 0) return (uint32_t)atoi(env);
+  const uint64_t slots = (uint64_t)num_cus * (uint64_t)ft.waves_per_cu;
+  uint32_t R = 4;
+  while (R < max_seg_packets && (uint64_t)S * ((max_seg_packets + R - 1) / R) > slots) ++R;
+  return R;
+}
+
+static inline hipError_t fused_launch(const ConstHeader& H, const FusedArgs& a, uint32_t max_seg_packets, hipStream_t s) {
+  const uint32_t runs = (max_seg_packets + a.R - 1) / a.R;
+  dim3 grid((runs + FUSED_WAVES - 1) / FUSED_WAVES, a.S);
+  if (H.channels == 1) vsyn_fused_long_kernel<1><<<grid, FUSED_WAVES * 64, 0, s>>>(a);
+  else vsyn_fused_long_kernel<2><<<grid, FUSED_WAVES * 64, 0, s>>>(a);
+  return hipGetLastError();
+}
+
 static inline hipError_t fused_imdct_launch(const ConstHeader&, const uint8_t*, const FusedTables&, int, uint32_t, uint32_t,
                                             const float*, float*, hipStream_t, bool* done) {
   *done = false;

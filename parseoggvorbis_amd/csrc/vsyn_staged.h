@@ -27,11 +27,25 @@ __device__ __forceinline__ AbsScan abs_combine(AbsScan a, AbsScan b) {
   return r;
 }
 
+// Shared by the layout kernel (which builds the staged list) and the fused kernel (which skips non-fast runs):
+// both must take the same decision.
+__device__ __forceinline__ bool run_is_fast(const ConstHeader* H, const vsyn_packet* __restrict__ spk, uint32_t qa, uint32_t qb,
+                                            uint32_t carry_n, uint32_t fused_ok) {
+  if (!fused_ok) return false;
+  if (qa == 0 && carry_n) return false;  // a carry-in from an earlier submit is in natural order: staged kernels take that run
+  for (uint32_t q = qa ? qa - 1 : 0; q < qb; ++q) {
+    const uint32_t m = spk[q].mode;
+    if (!(m < H->num_modes && H->mode_blockflag[m])) return false;
+  }
+  return true;
+}
+
 __global__ void __launch_bounds__(256)
 vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet* __restrict__ pk, uint32_t S,
                    const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
                    SegInfo* __restrict__ sinfo, StreamState* __restrict__ state, uint32_t* __restrict__ emit_len,
-                   DevStatus* __restrict__ status) {
+                   DevStatus* __restrict__ status, uint32_t R, uint32_t fused_ok, uint32_t* __restrict__ staged_list,
+                   uint32_t* __restrict__ staged_count, uint32_t* __restrict__ seg_of_pkt) {
   const ConstHeader* H = hdr_of(cb);
   const uint32_t g = blockIdx.x, t = threadIdx.x;
   if (g >= S) return;
@@ -158,6 +172,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       pi.own = own;
       pi.used = used;
       info[p] = pi;
+      seg_of_pkt[p] = g;
       if (emit_len) emit_len[p] = emit;
       if (q == num - 1) {
         s_abs_end = abs_after;
@@ -169,6 +184,22 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     }
   }
   __syncthreads();
+
+  // pass C: classify runs of R packets. A run goes to the fused long-block kernel iff every packet it touches
+  // (its one-packet halo included) is a valid long block and any carry-in is a long block; all other runs are
+  // appended to the staged work list (entry = packet index | emit << 31; halo packets carry emit = 0).
+  {
+    const uint32_t nruns = (num + R - 1) / R;
+    for (uint32_t r = t; r < nruns; r += 256) {
+      const uint32_t qa = r * R, qb2 = min(num, qa + R);
+      if (run_is_fast(H, spk, qa, qb2, carry_n, fused_ok)) continue;
+      const bool prev_fast = qa > 0 && run_is_fast(H, spk, qa - R, qa, carry_n, fused_ok);
+      const uint32_t cnt = (qb2 - qa) + (prev_fast ? 1u : 0u);
+      uint32_t at = atomicAdd(staged_count, cnt);
+      if (prev_fast) staged_list[at++] = sg.first_packet + qa - 1;  // IMDCT only: the overlap of `qa` reads its block
+      for (uint32_t q = qa; q < qb2; ++q) staged_list[at++] = (sg.first_packet + q) | 0x80000000u;
+    }
+  }
   if (t == 0) {
     SegInfo si;
     si.has_carry = carry_n ? 1u : 0u;
@@ -298,16 +329,17 @@ __device__ __forceinline__ void inverse_couple(float& m, float& a) {  // hpp:122
 }
 
 __global__ void __launch_bounds__(256)
-vsyn_spectrum_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info,
-                     const float* __restrict__ residue, const uint16_t* __restrict__ fy, float* __restrict__ env,
-                     DevStatus* __restrict__ status) {
+vsyn_spectrum_kernel(const uint8_t* __restrict__ cb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                     const PktInfo* __restrict__ info, const float* __restrict__ residue, const uint16_t* __restrict__ fy,
+                     float* __restrict__ env, DevStatus* __restrict__ status) {
   const ConstHeader* H = hdr_of(cb);
-  const uint32_t p = blockIdx.x;  // grid.x carries the packet index (grid.y/z are limited to 65535)
+  const uint32_t total = *count;
+  for (uint32_t li = blockIdx.x; li < total; li += gridDim.x) {  // grid-stride over the staged work list
+  const uint32_t p = list[li] & 0x7FFFFFFFu;
   const PktInfo pi = info[p];
-  if (pi.bad) return;
+  if (pi.bad) continue;
   const uint32_t n2 = pi.n / 2u, C = H->channels;
-  const uint32_t i = blockIdx.y * 256 + threadIdx.x;
-  if (i >= n2) return;
+  for (uint32_t i = threadIdx.x; i < n2; i += 256) {
   const float* src = residue + pi.res_off;
   float* dst = env + pi.res_off;
   for (uint32_t c = 0; c < C; ++c) dst[(size_t)c * n2 + i] = src[(size_t)c * n2 + i];
@@ -334,6 +366,8 @@ vsyn_spectrum_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* 
       }
     }
     dst[(size_t)c * n2 + i] *= f;
+  }
+  }
   }
 }
 
@@ -394,17 +428,20 @@ __device__ void imdct_block_lds(const uint8_t* __restrict__ cb, int b, uint32_t 
 }
 
 __global__ void __launch_bounds__(256)
-vsyn_imdct_staged_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info,
-                         const float* __restrict__ env, float* __restrict__ blk) {
+vsyn_imdct_staged_kernel(const uint8_t* __restrict__ cb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                         const PktInfo* __restrict__ info, const float* __restrict__ env, float* __restrict__ blk) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   const ConstHeader* H = hdr_of(cb);
-  const uint32_t p = blockIdx.x / H->channels, c = blockIdx.x % H->channels;
-  const PktInfo pi = info[p];
-  if (pi.bad) return;
-  const uint32_t n = pi.n;
-  float2* bufA = (float2*)lds_raw;
-  float2* bufB = bufA + n / 4;
-  imdct_block_lds(cb, pi.lng, n, env + pi.res_off + (size_t)c * (n / 2), blk + 2 * pi.res_off + (size_t)c * n, bufA, bufB);
+  const uint32_t C = H->channels, total = *count * C;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const uint32_t p = list[w / C] & 0x7FFFFFFFu, c = w % C;
+    const PktInfo pi = info[p];
+    if (pi.bad) continue;
+    const uint32_t n = pi.n;
+    float2* bufA = (float2*)lds_raw;
+    float2* bufB = bufA + n / 4;
+    imdct_block_lds(cb, pi.lng, n, env + pi.res_off + (size_t)c * (n / 2), blk + 2 * pi.res_off + (size_t)c * n, bufA, bufB);
+  }
 }
 
 // plain [count][n/2] -> [count][n] (BASELINE config 2), generic version
@@ -426,16 +463,20 @@ vsyn_imdct_plain_kernel(const uint8_t* __restrict__ cb, int b, uint32_t n, uint3
 // The last packet of a segment also stores its windowed right half as the stream's carry.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-vsyn_overlap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info, uint32_t S,
-                    const vsyn_segment* __restrict__ segs, const SegInfo* __restrict__ sinfo, const uint32_t* __restrict__ seg_of_pkt,
-                    const float* __restrict__ blk, float* __restrict__ pcm, uint64_t plane_stride, float* __restrict__ carry) {
+vsyn_overlap_kernel(const uint8_t* __restrict__ cb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                    const PktInfo* __restrict__ info, const vsyn_segment* __restrict__ segs, const SegInfo* __restrict__ sinfo,
+                    const uint32_t* __restrict__ seg_of_pkt, const float* __restrict__ blk, float* __restrict__ pcm,
+                    uint64_t plane_stride, float* __restrict__ carry) {
   const ConstHeader* H = hdr_of(cb);
-  const uint32_t p = blockIdx.x, c = blockIdx.y, C = H->channels;
-  const uint32_t s = blockIdx.z * 256 + threadIdx.x;
+  const uint32_t C = H->channels, total = *count * C;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+  const uint32_t entry = list[w / C], c = w % C;
+  if (!(entry >> 31)) continue;  // halo entry: block only
+  const uint32_t p = entry & 0x7FFFFFFFu;
   const uint32_t g = seg_of_pkt[p];
-  if (g == 0xFFFFFFFFu) return;
   const PktInfo pi = info[p];
-  if (pi.bad) return;
+  if (pi.bad) continue;
+  for (uint32_t s = threadIdx.x; s < H->bs[1] / 2; s += 256) {
   const vsyn_segment sg = segs[g];
   const SegInfo si = sinfo[g];
   const uint32_t q = p - sg.first_packet, n = pi.n, half1 = H->bs[1] / 2;
@@ -472,14 +513,7 @@ vsyn_overlap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* _
     float* cout = carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * half1;
     cout[s] = cur[n / 2 + s] * wc[n / 2 + s];
   }
+  }
+  }
 }
 
-// packet -> segment map for the gather kernel (segments are few; packets many)
-__global__ void __launch_bounds__(256)
-vsyn_segmap_kernel(uint32_t P, uint32_t S, const vsyn_segment* __restrict__ segs, uint32_t* __restrict__ seg_of_pkt) {
-  const uint32_t g = blockIdx.y;
-  if (g >= S) return;
-  const vsyn_segment sg = segs[g];
-  if ((uint64_t)sg.first_packet + sg.num_packets > P) return;
-  for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < sg.num_packets; q += gridDim.x * 256) seg_of_pkt[sg.first_packet + q] = g;
-}

@@ -126,7 +126,11 @@ def test_streaming_across_submits(flags):
         assert r["rc"] == 0
         assert np.array_equal(r["emit_len"], one["emit_len"][a:e])
         parts.append(r["pcm"][0][:, :int(r["emit_len"].sum())])
-    assert np.array_equal(np.concatenate(parts, axis=1), one["pcm"][0][:, :total])  # same kernels, same bits
+    got = np.concatenate(parts, axis=1)
+    if flags:  # staged kernels everywhere: same arithmetic, same bits
+        assert np.array_equal(got, one["pcm"][0][:, :total])
+    else:      # a run that continues a stream from an earlier submit takes the staged kernels, the rest the fused one
+        assert np.abs(got - one["pcm"][0][:, :total]).max() < TOL
 
 
 def test_empty_and_ragged_batches():
@@ -191,7 +195,7 @@ def test_imdct_only(n):
     import torch
     count = 4096 if n == 256 else 257
     rng = np.random.default_rng(1234)
-    x = (rng.standard_normal((count, n // 2)) * 0.05 * np.sqrt(128.0 / (n // 2))).astype(np.float32)
+    x = (rng.standard_normal((count, n // 2)) * 0.05 * np.sqrt(128.0 / max(128, n // 2))).astype(np.float32)  # |out| <~ 1
     spec = fixture_like_spec(1, min(n, 256) if n != 64 else 64, max(n, 256) if n != 64 else 64)
     if n not in (spec.blocksize0, spec.blocksize1):
         spec = fixture_like_spec(1, n, n)
@@ -202,7 +206,7 @@ def test_imdct_only(n):
     torch.cuda.synchronize()
     got = dout.cpu().numpy()
     want = ob.imdct(n, x)
-    assert np.abs(want).max() < 2.0
+    assert np.abs(want).max() < 1.5
     assert np.abs(got - want).max() < TOL
     # analytic oracle on a few rows (double-precision closed form)
     cf = np.empty(n, np.float64)
