@@ -95,6 +95,9 @@ struct vsyn_handle {
   FusedTables fused{};
   bool fused_ok = false;
   int num_cus = 256;
+  hipStream_t side = nullptr;          // the (usually empty) staged work list runs beside the fused kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  uint32_t submit_parity = 0;
   // workspace
   DevBuf<uint32_t> ws_list;   // staged work list (+ its counter in slot 0 of ws_count)
   DevBuf<uint32_t> ws_count;
@@ -196,6 +199,11 @@ static int build_const(const vsyn_setup* su, uint32_t max_streams, vsyn_handle* 
       if (lo < 0 || hi < 0) return fail(err, VSYN_ERR_INVALID, "floor %u: post %u has no low/high neighbour (xs[1] must be the maximum)", f, i);
       fc.lo[i] = (uint8_t)lo;
       fc.hi[i] = (uint8_t)hi;
+      fc.pk[i].lo = (uint16_t)lo;
+      fc.pk[i].hi = (uint16_t)hi;
+      fc.pk[i].dxi = (uint16_t)(sf.xs[i] - sf.xs[lo]);
+      fc.pk[i].adx = (uint16_t)(sf.xs[hi] - sf.xs[lo]);
+      fc.pk[i].inv_adx = 1.0f / (float)(sf.xs[hi] - sf.xs[lo]);
     }
   }
   H.ys_stride = (maxp + 3u) & ~3u;
@@ -320,6 +328,11 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   DevStatus init = {0u, 0xFFFFFFFFu};
   HC(hipMemcpy(h->d_status, &init, sizeof(init), hipMemcpyHostToDevice));
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HC(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  HC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  HC(h->ws_count.ensure(4));
+  HC(hipMemset(h->ws_count.p, 0, sizeof(uint32_t) * 4));
   h->fused_ok = fused_setup_ok(h->H, h->host_const.data());
   if ((e = fused_tables_create(h->H, h->host_const.data(), &h->fused)) != hipSuccess) {
     fail(err, VSYN_ERR_HIP, "fused table upload failed: %s", hipGetErrorString(e));
@@ -335,6 +348,9 @@ void vsyn_destroy(vsyn_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   fused_tables_destroy(&h->fused);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->d_const) (void)hipFree(h->d_const);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_carry) (void)hipFree(h->d_carry);
@@ -445,23 +461,59 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   HIPCHK(h->ws_seg.ensure(S));
   HIPCHK(h->ws_segmap.ensure(P));
   HIPCHK(h->ws_list.ensure(2 * (size_t)P + 64));
-  HIPCHK(h->ws_count.ensure(4));
   uint16_t* fy = taps && taps->floor_final ? taps->floor_final : nullptr;
   if (!fy) {
     HIPCHK(h->ws_fy.ensure((size_t)P * C * H.ys_stride));
     fy = h->ws_fy.p;
   }
 
-  HIPCHK(hipMemsetAsync(h->ws_count.p, 0, sizeof(uint32_t) * 4, s));
+  uint32_t* cnt = h->ws_count.p + (h->submit_parity & 1u);
+  uint32_t* cnt_next = h->ws_count.p + ((h->submit_parity & 1u) ^ 1u);
+  h->submit_parity ^= 1u;
   vsyn_layout_kernel<<<S, 256, 0, s>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, h->ws_info.p, h->ws_seg.p,
-                                       h->d_state, d_emit_len, h->d_status, R, force_staged ? 0u : 1u, h->ws_list.p,
-                                       h->ws_count.p, h->ws_segmap.p);
-  vsyn_floor_unwrap_kernel<<<(P * C + 255) / 256, 256, 0, s>>>(h->d_const, P, h->ws_info.p, d_ys, fy, h->d_status);
+                                       h->d_state, d_emit_len, h->d_status, R, force_staged ? 0u : 1u, h->ws_list.p, cnt,
+                                       cnt_next, h->ws_segmap.p);
+  {
+    const uint32_t rows = P * C;
+    vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, s>>>(
+        h->d_const, P, nullptr, nullptr, h->ws_info.p, d_ys, fy, h->d_status);
+  }
 
+  // staged kernels walk the work list the layout kernel built: everything when forced, otherwise only the runs the
+  // fused kernel declines (short / mixed blocks, carry-in). In fused mode they run on a forked side stream beside the
+  // fused kernel (disjoint outputs) and exit at once when the list is empty.
+  hipStream_t ss = force_staged ? s : h->side;
   if (!force_staged) {
+    HIPCHK(hipEventRecord(h->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  }
+  {
+    const size_t bound = (size_t)P * C * (H.bs[1] / 2);  // residue floats upper bound (device-resident descriptors)
+    float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
+    float* blk = taps && taps->pcm_after_mdct ? taps->pcm_after_mdct : nullptr;
+    if (!env) {
+      HIPCHK(h->ws_env.ensure(bound));
+      env = h->ws_env.p;
+    }
+    if (!blk) {
+      HIPCHK(h->ws_blk.ensure(2 * bound));
+      blk = h->ws_blk.p;
+    }
+    const uint32_t grid = force_staged ? std::min<uint32_t>(P * C, 256u * 32u) : 512u;
+    vsyn_spectrum_kernel<<<std::min<uint32_t>(grid, P), 256, 0, ss>>>(h->d_const, h->ws_list.p, cnt, h->ws_info.p, d_residue, fy, env,
+                                                                    h->d_status);
+    if (force_staged) HIPCHK(profile_begin(h, s, "vsyn_imdct_staged_kernel"));
+    vsyn_imdct_staged_kernel<<<grid, 256, (size_t)H.bs[1] * 4, ss>>>(h->d_const, h->ws_list.p, cnt, h->ws_info.p, env, blk);
+    if (force_staged) HIPCHK(profile_end(h, s));
+    vsyn_overlap_kernel<<<grid, 256, 0, ss>>>(h->d_const, h->ws_list.p, cnt, h->ws_info.p, d_segments, h->ws_seg.p, h->ws_segmap.p, blk,
+                                             d_pcm, plane_stride, h->d_carry);
+  }
+  if (!force_staged) {
+    HIPCHK(hipEventRecord(h->ev_join, h->side));
     FusedArgs a;
     a.cb = h->d_const;
     a.binseg = h->fused.d_binseg;
+    a.lds_image = h->fused.d_lds;
     a.packets = d_packets;
     a.segs = d_segments;
     a.info = h->ws_info.p;
@@ -479,29 +531,7 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     hipError_t e = fused_launch(H, a, max_seg_packets, s);
     if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
     HIPCHK(profile_end(h, s));
-  }
-  {
-    // staged kernels walk the work list the layout kernel built (everything when forced, otherwise only the runs
-    // the fused kernel declines: short / mixed blocks); with an empty list they exit at once
-    const size_t bound = (size_t)P * C * (H.bs[1] / 2);  // residue floats upper bound (device-resident descriptors)
-    float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
-    float* blk = taps && taps->pcm_after_mdct ? taps->pcm_after_mdct : nullptr;
-    if (!env) {
-      HIPCHK(h->ws_env.ensure(force_staged ? bound : std::min(bound, h->ws_env.cap ? h->ws_env.cap : bound)));
-      env = h->ws_env.p;
-    }
-    if (!blk) {
-      HIPCHK(h->ws_blk.ensure(force_staged ? 2 * bound : std::min(2 * bound, h->ws_blk.cap ? h->ws_blk.cap : 2 * bound)));
-      blk = h->ws_blk.p;
-    }
-    const uint32_t grid = force_staged ? std::min<uint32_t>(P * C, 256u * 32u) : 1024u;
-    vsyn_spectrum_kernel<<<std::min<uint32_t>(grid, P), 256, 0, s>>>(h->d_const, h->ws_list.p, h->ws_count.p, h->ws_info.p, d_residue, fy,
-                                                                   env, h->d_status);
-    if (force_staged) HIPCHK(profile_begin(h, s, "vsyn_imdct_staged_kernel"));
-    vsyn_imdct_staged_kernel<<<grid, 256, (size_t)H.bs[1] * 4, s>>>(h->d_const, h->ws_list.p, h->ws_count.p, h->ws_info.p, env, blk);
-    if (force_staged) HIPCHK(profile_end(h, s));
-    vsyn_overlap_kernel<<<grid, 256, 0, s>>>(h->d_const, h->ws_list.p, h->ws_count.p, h->ws_info.p, d_segments, h->ws_seg.p,
-                                             h->ws_segmap.p, blk, d_pcm, plane_stride, h->d_carry);
+    HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   }
   HIPCHK(hipGetLastError());
   return VSYN_OK;

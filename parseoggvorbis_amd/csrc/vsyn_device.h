@@ -25,6 +25,12 @@ struct FloorConst {               // one floor-1 configuration (VorbisFloor1, hp
   uint8_t sorted_idx[VSYN_MAX_POSTS + 3];  // sorted position -> header index
   uint8_t lo[VSYN_MAX_POSTS + 3];          // low_neighbor(xs,i)  (Utils.hpp:60-87), header indices
   uint8_t hi[VSYN_MAX_POSTS + 3];          // high_neighbor(xs,i) (Utils.hpp:91-118)
+  struct PostK {                           // per-post constants of step 1, one 16-byte load per post
+    uint16_t lo, hi;                       // neighbour header indices
+    uint16_t dxi, adx;                     // xs[i] - xs[lo], xs[hi] - xs[lo]
+    float inv_adx;                         // 1 / adx
+    uint32_t pad;
+  } pk[VSYN_MAX_POSTS + 1];
 };
 
 struct MapConst {                 // VorbisMapping (hpp:765-814), synthesis-relevant part

@@ -22,17 +22,31 @@
 
 #include "vsyn_device.h"
 
-#define FUSED_WAVES 4     // waves per workgroup (tables are shared per workgroup)
+#define FUSED_WAVES 8     // waves per workgroup (tables are shared per workgroup)
 #define FUSED_XSLOTS 576  // float2 slots of the per-wave exchange image: 8 rows x 72 (>= 8 x 65)
+
+// Read-only LDS image of the fused kernel, built once per handle on the host in exactly the order the lanes read
+// it (every table is lane-major: lane l of a wave-instruction reads element [..][l], so all reads are conflict-free).
+struct FusedLdsImage {
+  float2 pre[8][64];      // pre-rotation   exp(-i pi (4k+1)/(4M)),  k = lane + 64 t
+  float2 post[8][64];     // post-rotation  exp(-i pi m / M),        m = swap3(lane) + 64 k
+  float2 tw1[8][64];      // W512^(lane * t)        (row 0 unused)
+  float2 tw2[8][8];       // W64^(c * a), c = lane & 7 (row 0 unused)
+  float win[2][2][8][64]; // [prev/next flag][0: at s, 1: at 1023-s][k][lane]: left half of the long window at the
+                          // output sample s of point m; the right half for next flag f is its mirror (hpp:850-859)
+  float invdb[256];       // Vorbis I 10.1 (hpp:588)
+};
 
 struct FusedTables {
   uint8_t* d_binseg = nullptr;  // [num_floors][bs1/2]: sorted-post interval containing bin x
-  int waves_per_cu = 16;
+  FusedLdsImage* d_lds = nullptr;
+  int waves_per_cu = 12;
 };
 
 struct FusedArgs {
   const uint8_t* cb;
   const uint8_t* binseg;
+  const FusedLdsImage* lds_image;
   const vsyn_packet* packets;
   const vsyn_segment* segs;
   const PktInfo* info;
@@ -76,11 +90,11 @@ __device__ __forceinline__ void dft8(float2 (&x)[8]) {
 
 // FFT-512 across one wave: in: lane l holds z[t] = point l + 64 t; out: lane l holds Z[c'] = bin swap3(l) + 64 c'.
 // xb = this wave's exchange image (FUSED_XSLOTS float2), w = W512^j table (LDS).
-__device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__ xb, const float2* __restrict__ w, uint32_t lane) {
+__device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__ xb, const FusedLdsImage* __restrict__ T, uint32_t lane) {
   const uint32_t c = lane & 7u, hi = lane >> 3;
   dft8(z);  // over t -> t'
 #pragma unroll
-  for (int t = 1; t < 8; ++t) z[t] = cmulf(z[t], w[lane * t]);
+  for (int t = 1; t < 8; ++t) z[t] = cmulf(z[t], T->tw1[t][lane]);
   // exchange 1: element (t', a, c): lane 8a+c reg t'  ->  lane 8t'+c reg a.   row stride 72: conflict-free both ways
 #pragma unroll
   for (int t = 0; t < 8; ++t) xb[t * 72 + lane] = z[t];
@@ -88,7 +102,7 @@ __device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__
   for (int a = 0; a < 8; ++a) z[a] = xb[hi * 72 + a * 8 + c];
   dft8(z);  // over a -> a'
 #pragma unroll
-  for (int a = 1; a < 8; ++a) z[a] = cmulf(z[a], w[8 * c * a]);  // W64^(c a')
+  for (int a = 1; a < 8; ++a) z[a] = cmulf(z[a], T->tw2[a][c]);  // W64^(c a')
   // exchange 2: element (h, a', c): lane 8h+c reg a'  ->  lane 8h+a' reg c.   row stride 65
 #pragma unroll
   for (int a = 0; a < 8; ++a) xb[a * 65 + lane] = z[a];
@@ -97,48 +111,29 @@ __device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__
   dft8(z);  // over c -> c'
 }
 
-__device__ __forceinline__ void couple2(float& m, float& a) {  // hpp:1220-1239
-  float m2 = m, a2 = a;
-  if (m > 0.f) {
-    if (a > 0.f) a2 = m - a;
-    else { a2 = m; m2 = m + a; }
-  } else {
-    if (a > 0.f) a2 = m + a;
-    else { a2 = m; m2 = m - a; }
-  }
-  m = m2;
-  a = a2;
+// hpp:1220-1239, branch-free (selects only; same comparisons, same single add/sub per output, so bit-identical):
+//   d = m > 0 ? a : -a;   a > 0 ? (M, A) = (m, m - d) : (M, A) = (m + d, m)
+__device__ __forceinline__ void couple2(float& m, float& a) {
+  const float d = m > 0.f ? a : -a;
+  const float x = m - d, y = m + d;
+  const bool ap = a > 0.f;
+  a = ap ? x : m;
+  m = ap ? m : y;
 }
 
 template <int C>
-__global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(const FusedArgs A) {
-  constexpr uint32_t M = 1024, N4 = 512;
-  __shared__ float2 s_pre[N4], s_post[N4], s_w[N4];
-  __shared__ float s_win[2][M];  // left half of the long window for prev flag = 0 / 1; the right half for
-                                 // next flag = f is its mirror image (hpp:850-859 build both from one formula)
-  __shared__ float s_invdb[256];
+__global__ void __launch_bounds__(FUSED_WAVES * 64, 4) vsyn_fused_long_kernel(const FusedArgs A) {
+  constexpr uint32_t M = 1024;
+  __shared__ FusedLdsImage s_t;
   __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
   __shared__ float4 s_seg[FUSED_WAVES][C][64];
 
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
   {
-    const float2* pre = pre_of(cb, 1);
-    const float2* post = post_of(cb, 1);
-    const float2* tw = fft_of(cb, 1);
-    const float* w0 = win_of(cb, 1, 0);  // prev = short
-    const float* w1 = win_of(cb, 1, 1);  // prev = long
-    const float* idb = invdb_of(cb);
-    for (uint32_t i = threadIdx.x; i < N4; i += FUSED_WAVES * 64) {
-      s_pre[i] = pre[i];
-      s_post[i] = post[i];
-      s_w[i] = tw[i];
-    }
-    for (uint32_t i = threadIdx.x; i < M; i += FUSED_WAVES * 64) {
-      s_win[0][i] = w0[i];
-      s_win[1][i] = w1[i];
-    }
-    for (uint32_t i = threadIdx.x; i < 256; i += FUSED_WAVES * 64) s_invdb[i] = idb[i];
+    const uint4* src = (const uint4*)A.lds_image;
+    uint4* dst = (uint4*)&s_t;
+    for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
   }
   __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
 
@@ -164,7 +159,6 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(co
   for (int c = 0; c < C; ++c)
 #pragma unroll
     for (int k = 0; k < 8; ++k) P[c][k] = 0.f;
-  bool have_prev = false;
   uint32_t prev_next_long = 1;
 
   uint32_t bseg[C][4];
@@ -199,6 +193,7 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(co
     }
 
     // ---- floor-1 step 2 set-up: one table entry per sorted-post interval (hpp:563-584) ---------------------
+    bool floor_bad = false;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       if (!((pi.own >> c) & 1u)) continue;
@@ -229,25 +224,33 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(co
       const uint32_t packed = (xs << 16) | (v & 0x7FFFu);
       const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
       const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
-      const float x0 = (float)(plo >> 16), y0 = (float)(plo & 0xFFFFu);
-      const float x1 = (float)(phi >> 16), y1 = (float)(phi & 0xFFFFu);
+      // segment (x0,y0)-(x1,y1) in slope/intercept form: curve(x) = y0 + sgn * floor(x*A + B) with
+      // A = |dy|/adx, B = (0.5 - |dy| x0)/adx  ==  y0 +- (|dy| (x - x0)) / adx  in integers (Utils.hpp:122-137);
+      // the +0.5/adx guard band (>= 4.9e-4) dwarfs the f32 rounding of x*A + B (<= 6e-5 for x < 1024), DESIGN.md
+      floor_bad |= (v & 0x7FFFu) > 255u;  // a flagged or unflagged post above 255 can only render >= 256 (hpp:587)
+      const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
+      const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
+      const float inv = has_hi ? 1.0f / (x1 - x0) : 0.f;
+      const float ady = fabsf(y1 - y0);
       float4 e;
-      e.x = x0;
-      e.y = y0;
-      e.z = has_hi ? y1 - y0 : 0.f;
-      e.w = has_hi ? 1.0f / (x1 - x0) : 0.f;
+      e.x = ady * inv;
+      e.y = __builtin_fmaf(-ady, x0, 0.5f) * inv;
+      e.z = y1 >= y0 ? 1.f : -1.f;
+      e.w = y0;
       s_seg[wave][c][lane] = e;
     }
 
     // ---- inverse coupling (hpp:1213-1241): at most one (magnitude, angle) step in this kernel ----------------
     if (C == 2 && mc->ncoup) {
-      const bool swap = mc->coup[0] != 0;  // magnitude channel is 1
+      if (mc->coup[0] == 0) {  // magnitude = channel 0 (one wave-uniform branch, not one per bin)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        if (!swap) {
+        for (int t = 0; t < 8; ++t) {
           couple2(r[0][t].x, r[C - 1][t].x);
           couple2(r[0][t].y, r[C - 1][t].y);
-        } else {
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
           couple2(r[C - 1][t].x, r[0][t].x);
           couple2(r[C - 1][t].y, r[0][t].y);
         }
@@ -255,10 +258,10 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(co
     }
 
     const uint32_t emit = halo ? 0u : pi.emit;
-    const float* TL = s_win[pi.widx & 1u];       // this block's left-half window
-    const float* TR = s_win[prev_next_long];     // previous block's right-half window, mirrored
+    const float (*TL)[8][64] = s_t.win[pi.widx & 1u];    // this block's left-half window
+    const float (*TR)[8][64] = s_t.win[prev_next_long];  // previous block's right-half window, mirrored
     const uint32_t cur_next_long = (pi.widx >> 1) & 1u;
-    bool floor_bad = false;
+    const float xf0 = (float)(2u * lane);
 
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -276,12 +279,8 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(co
               const int b = 2 * t + e;
               const uint32_t sidx = (bseg[c][b >> 2] >> (8 * (b & 3))) & 0xFFu;
               const float4 sgm = s_seg[wave][c][sidx];
-              const float xf = (float)(2u * (lane + 64u * t) + e);
-              const float err = fabsf(sgm.z) * (xf - sgm.x);                     // exact: < 2^24
-              const float qf = floorf(__builtin_fmaf(err, sgm.w, 0.5f * sgm.w));  // == (ady*dx)/adx, see DESIGN.md
-              const float y = sgm.y + copysignf(qf, sgm.z);
-              floor_bad |= !(y >= 0.f && y < 256.f);  // hpp:587
-              fl2[e] = s_invdb[(uint32_t)fminf(fmaxf(y, 0.f), 255.f)];
+              const float qf = floorf(__builtin_fmaf(xf0 + (float)(128 * t + e), sgm.x, sgm.y));
+              fl2[e] = s_t.invdb[(uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w)];  // in 0..255: between two posts <= 255
             }
             r[c][t] = f2(r[c][t].x * fl2[0], r[c][t].y * fl2[1]);
             if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep the LDS gathers from being hoisted en bloc
@@ -294,35 +293,28 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(co
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const float im = __shfl(r[c][7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
-        z[t] = cmulf(f2(r[c][t].x, im), s_pre[lane + 64 * t]);
+        z[t] = cmulf(f2(r[c][t].x, im), s_t.pre[t][lane]);
       }
-      fft512_wave(z, xb, s_w, lane);
+      fft512_wave(z, xb, &s_t, lane);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], s_post[kappa + 64 * k]);
+      for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], s_t.post[k][lane]);
 
       // ---- window + overlap-add + PCM store (hpp:1008-1059) ------------------------------------------------
       // point m = kappa + 64k gives samples s and 1023-s of this packet's output:
       //   out[s]      = fl(P*wr(s))      + fl( cc*wl(s))        cc =  u_cur[512+s]
       //   out[1023-s] = fl(P*wr(1023-s)) + fl(-cc*wl(1023-s))   P  = -u_prev[511-s]
       float o_s[8], o_m[8];
+      if (emit) {  // P is zero until the run has seen a block, and 0*w + x == x exactly as in `buf = 0; buf += x`
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t m = kappa + 64u * k;
-        const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
-        const float cc = k >= 4 ? z[k].x : -z[k].y;
-        const float pn = k >= 4 ? z[k].y : -z[k].x;
-        if (emit) {
-          const float wl_s = TL[s], wl_m = TL[1023u - s];
-          float tp_s = 0.f, tp_m = 0.f;
-          if (have_prev) {
-            tp_s = P[c][k] * TR[1023u - s];
-            tp_m = P[c][k] * TR[s];
-          }
-          o_s[k] = tp_s + cc * wl_s;
-          o_m[k] = tp_m + (-cc) * wl_m;
+        for (int k = 0; k < 8; ++k) {
+          const float cc = k >= 4 ? z[k].x : -z[k].y;
+          const float tp_s = P[c][k] * TR[1][k][lane], tp_m = P[c][k] * TR[0][k][lane];
+          o_s[k] = tp_s + cc * TL[0][k][lane];
+          o_m[k] = tp_m + (-cc) * TL[1][k][lane];
         }
-        P[c][k] = pn;
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) P[c][k] = k >= 4 ? z[k].y : -z[k].x;
       if (emit) {
         float* out = A.pcm + ((size_t)g * C + c) * A.plane_stride + pi.out_pos;
         const bool fast_store = emit == M && (((uintptr_t)out & 7u) == 0);
@@ -345,18 +337,17 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 3) vsyn_fused_long_kernel(co
       }
       if (q == num - 1) {  // stream carry for the next submit: windowed right half, natural order
         float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * M;
-        const float* TN = s_win[cur_next_long];
+        const float (*TN)[8][64] = s_t.win[cur_next_long];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const uint32_t m = kappa + 64u * k;
           const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
-          cout[s] = P[c][k] * TN[1023u - s];
-          cout[1023u - s] = P[c][k] * TN[s];
+          cout[s] = P[c][k] * TN[1][k][lane];
+          cout[1023u - s] = P[c][k] * TN[0][k][lane];
         }
       }
     }
     if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
-    have_prev = true;
     prev_next_long = cur_next_long;
   }
 }
@@ -394,6 +385,36 @@ static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t
   if (e != hipSuccess) return e;
   e = hipMemcpy(ft->d_binseg, tab.data(), tab.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) return e;
+  if (fused_supported(H)) {
+    std::vector<FusedLdsImage> imgv(1);
+    FusedLdsImage& im = imgv[0];
+    memset(&im, 0, sizeof(im));
+    const float2* pre = (const float2*)(host_const + H.off_pre[1]);
+    const float2* post = (const float2*)(host_const + H.off_post[1]);
+    const float2* tw = (const float2*)(host_const + H.off_fft[1]);
+    const float* win = (const float*)(host_const + H.off_win[1]);
+    for (uint32_t l = 0; l < 64; ++l) {
+      const uint32_t kappa = ((l & 7u) << 3) | (l >> 3);
+      for (uint32_t k = 0; k < 8; ++k) {
+        im.pre[k][l] = pre[l + 64 * k];
+        im.post[k][l] = post[kappa + 64 * k];
+        im.tw1[k][l] = tw[(l * k) & 511u];
+        const uint32_t m = kappa + 64 * k;
+        const uint32_t s = k >= 4 ? 2 * m - 512 : 511 - 2 * m;
+        for (uint32_t f = 0; f < 2; ++f) {  // window table index = prev + 2*next: left half depends on prev only
+          im.win[f][0][k][l] = win[(size_t)f * H.bs[1] + s];
+          im.win[f][1][k][l] = win[(size_t)f * H.bs[1] + 1023 - s];
+        }
+      }
+    }
+    for (uint32_t a = 0; a < 8; ++a)
+      for (uint32_t c = 0; c < 8; ++c) im.tw2[a][c] = tw[(8 * c * a) & 511u];
+    memcpy(im.invdb, host_const + H.off_invdb, sizeof(im.invdb));
+    e = hipMalloc((void**)&ft->d_lds, sizeof(FusedLdsImage));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(ft->d_lds, &im, sizeof(FusedLdsImage), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+  }
   int blocks = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vsyn_fused_long_kernel<2>, FUSED_WAVES * 64, 0) == hipSuccess && blocks > 0)
     ft->waves_per_cu = blocks * FUSED_WAVES;
@@ -402,7 +423,9 @@ static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t
 
 static inline void fused_tables_destroy(FusedTables* ft) {
   if (ft->d_binseg) (void)hipFree(ft->d_binseg);
+  if (ft->d_lds) (void)hipFree(ft->d_lds);
   ft->d_binseg = nullptr;
+  ft->d_lds = nullptr;
 }
 
 static inline const char* fused_kernel_name(const ConstHeader&) { return "vsyn_fused_long_kernel"; }

@@ -45,10 +45,11 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
                    const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
                    SegInfo* __restrict__ sinfo, StreamState* __restrict__ state, uint32_t* __restrict__ emit_len,
                    DevStatus* __restrict__ status, uint32_t R, uint32_t fused_ok, uint32_t* __restrict__ staged_list,
-                   uint32_t* __restrict__ staged_count, uint32_t* __restrict__ seg_of_pkt) {
+                   uint32_t* __restrict__ staged_count, uint32_t* __restrict__ next_count, uint32_t* __restrict__ seg_of_pkt) {
   const ConstHeader* H = hdr_of(cb);
   const uint32_t g = blockIdx.x, t = threadIdx.x;
   if (g >= S) return;
+  if (g == 0 && t == 0) *next_count = 0;  // the other submit parity's list counter (no memset node needed)
   const vsyn_segment sg = segs[g];
   const bool seg_ok = sg.stream < H->max_streams && (uint64_t)sg.first_packet + sg.num_packets <= P && (sg.residue_off & 3) == 0;
   if (!seg_ok) {
@@ -102,20 +103,48 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       prev_n = n;
     }
   }
-  s_abs[t] = agg;
-  s_res[t] = res;
-  __syncthreads();
-  if (t == 0) {  // 256-step serial exclusive scan: negligible next to the synthesis kernels
-    AbsScan run = {0, 0};
-    uint64_t r = 0;
-    for (int i = 0; i < 256; ++i) {
-      AbsScan a = s_abs[i];
-      uint64_t x = s_res[i];
-      s_abs[i] = run;
-      s_res[i] = r;
-      run = abs_combine(run, a);
-      r += x;
+  // exclusive scan over the 256 thread aggregates: wave-level shuffles, then the 4 wave totals through LDS
+  {
+    const uint32_t lane = t & 63u, wv = t >> 6;
+    AbsScan inc = agg;
+    uint64_t rinc = res;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      AbsScan o;
+      o.val = __shfl_up(inc.val, d);
+      o.set = __shfl_up(inc.set, d);
+      const uint64_t ro = __shfl_up(rinc, d);
+      if ((int)lane >= d) {
+        inc = abs_combine(o, inc);
+        rinc += ro;
+      }
     }
+    if (lane == 63) {
+      s_abs[wv] = inc;
+      s_res[wv] = rinc;
+    }
+    __syncthreads();
+    AbsScan pre = {0, 0};
+    uint64_t rpre = 0;
+    for (uint32_t w = 0; w < wv; ++w) {
+      pre = abs_combine(pre, s_abs[w]);
+      rpre += s_res[w];
+    }
+    // exclusive = (prefix of earlier waves) o (inclusive of lane-1)
+    AbsScan ex;
+    ex.val = __shfl_up(inc.val, 1);
+    ex.set = __shfl_up(inc.set, 1);
+    uint64_t rex = __shfl_up(rinc, 1);
+    if (lane == 0) {
+      ex.val = 0;
+      ex.set = 0;
+      rex = 0;
+    }
+    ex = abs_combine(pre, ex);
+    rex += rpre;
+    __syncthreads();
+    s_abs[t] = ex;
+    s_res[t] = rex;
   }
   __syncthreads();
 
@@ -238,60 +267,98 @@ __device__ __forceinline__ uint32_t render_point_u32(uint32_t x0, uint32_t y0, u
   return up ? y0 + off : y0 - off;
 }
 
-__global__ void __launch_bounds__(256)
-vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const PktInfo* __restrict__ info,
-                         const uint16_t* __restrict__ ys, uint16_t* __restrict__ fy_out, DevStatus* __restrict__ status) {
-  const ConstHeader* H = hdr_of(cb);
-  const uint32_t C = H->channels, stride = H->ys_stride;
-  const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= P * C) return;
-  const uint32_t p = gid / C, c = gid % C;
-  const PktInfo pi = info[p];
-  uint16_t* out = fy_out + (size_t)gid * stride;
-  if (pi.bad || !((pi.own >> c) & 1u)) return;
-  const FloorConst* fc = floor_of(cb, map_of(cb, pi.mapping)->chfloor[c]);
-  const uint16_t* row = ys + (size_t)gid * stride;
-  const uint32_t posts = fc->posts, range = fc->range, mult = fc->mult;
+// predicted = render_point(xs[lo], fy[lo], xs[hi], fy[hi], xs[i]) with the post geometry folded into the
+// per-floor constants dxi = xs[i]-xs[lo] and inv = 1/(xs[hi]-xs[lo]):  off = (|dy| * dxi) / adx  exactly, via
+// floor((|dy|*dxi + 0.5) * inv) while |dy|*dxi < 2^24 (always, for in-range amplitudes); else the integer divide.
+__device__ __forceinline__ uint32_t predict_post(uint32_t ylo, uint32_t yhi, uint32_t dxi, uint32_t adx, float inv) {
+  const bool up = yhi >= ylo;
+  const uint32_t ady = up ? yhi - ylo : ylo - yhi;
+  uint32_t off;
+  const uint32_t prod = ady * dxi;
+  // float path only where it is provably the integer quotient: prod + 0.5 exact (< 2^23) and the rounding of the
+  // product (<= 2.4e-7 * prod/adx) stays inside the 0.5/adx guard band (prod < 2^21); in-range amplitudes give
+  // prod <= 255 * 4096
+  if (ady < 65536u && prod < (1u << 21)) off = (uint32_t)(((float)prod + 0.5f) * inv);
+  else off = prod / adx;
+  return up ? ylo + off : ylo - off;
+}
 
-  uint32_t fy[VSYN_MAX_POSTS];
-  uint64_t flags_lo = 3;  // posts 0..63
-  uint32_t flag_64 = 0;   // post 64
-  fy[0] = row[0];
-  fy[1] = row[1];
-  bool bad = false;
-  for (uint32_t i = 2; i < posts; ++i) {
-    const uint32_t lo = fc->lo[i], hi = fc->hi[i];
-    const uint32_t predicted = render_point_u32(fc->xs[lo], fy[lo], fc->xs[hi], fy[hi], fc->xs[i]);
-    const uint32_t val = row[i];
-    if (predicted > range) {  // hpp:536
-      bad = true;
-      break;
+#define UNWRAP_THREADS 128
+__global__ void __launch_bounds__(UNWRAP_THREADS)
+vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                         const PktInfo* __restrict__ info, const uint16_t* __restrict__ ys, uint16_t* __restrict__ fy_out,
+                         DevStatus* __restrict__ status) {
+  // list == nullptr: rows are all (packet, channel) pairs; else rows come from the staged work list
+  __shared__ uint32_t s_fy[VSYN_MAX_POSTS][UNWRAP_THREADS];  // post-major: thread-contiguous, conflict-free
+  const ConstHeader* H = hdr_of(cb);
+  const uint32_t C = H->channels, stride = H->ys_stride, t = threadIdx.x;
+  const uint32_t rows = (list ? *count : P) * C;
+  for (uint32_t base = blockIdx.x * UNWRAP_THREADS; base < rows; base += gridDim.x * UNWRAP_THREADS) {
+    const uint32_t row = base + t;
+    if (row >= rows) continue;
+    const uint32_t p = list ? (list[row / C] & 0x7FFFFFFFu) : row / C, c = row % C;
+    const uint32_t gid = p * C + c;
+    const PktInfo pi = info[p];
+    if (pi.bad || !((pi.own >> c) & 1u)) continue;
+    const FloorConst* fc = floor_of(cb, map_of(cb, pi.mapping)->chfloor[c]);
+    uint16_t* out = fy_out + (size_t)gid * stride;
+    const uint32_t posts = fc->posts, range = fc->range, mult = fc->mult;
+    {  // whole coded row up front (16-byte loads; rows are 8-byte aligned multiples of 4 posts), values parked in LDS
+      const uint2* in8 = (const uint2*)(ys + (size_t)gid * stride);
+      for (uint32_t j = 0; j * 4 < posts; ++j) {
+        const uint2 w = in8[j];
+        s_fy[4 * j + 0][t] = w.x & 0xFFFFu;
+        if (4 * j + 1 < VSYN_MAX_POSTS) s_fy[4 * j + 1][t] = w.x >> 16;
+        if (4 * j + 2 < VSYN_MAX_POSTS) s_fy[4 * j + 2][t] = w.y & 0xFFFFu;
+        if (4 * j + 3 < VSYN_MAX_POSTS) s_fy[4 * j + 3][t] = w.y >> 16;
+      }
     }
-    const uint32_t high_room = range - predicted, low_room = predicted;
-    const uint32_t room = min(high_room, low_room) * 2;
-    uint32_t f;
-    if (val == 0) {
-      f = predicted;
-    } else {
-      flags_lo |= (1ull << lo) | (1ull << hi);  // lo, hi < i <= 64
-      if (i < 64) flags_lo |= 1ull << i; else flag_64 = 1;
-      if (val >= room)
-        f = high_room > low_room ? val - low_room + predicted : predicted - val + high_room - 1;
-      else
-        f = (val & 1u) ? predicted - (val + 1) / 2 : predicted + val / 2;
+    uint64_t flags_lo = 3;
+    uint32_t flag_64 = 0;
+    bool bad = false;
+    for (uint32_t i = 2; i < posts; ++i) {
+      const uint4 kq = *(const uint4*)&fc->pk[i];
+      const uint32_t lo = kq.x & 0xFFFFu, hi = kq.x >> 16;
+      const uint32_t val = s_fy[i][t];  // coded value; overwritten below by the amplitude
+      const uint32_t predicted = predict_post(s_fy[lo][t], s_fy[hi][t], kq.y & 0xFFFFu, kq.y >> 16, __uint_as_float(kq.z));
+      if (predicted > range) {  // hpp:536
+        bad = true;
+        break;
+      }
+      const uint32_t high_room = range - predicted, low_room = predicted;
+      const uint32_t room = min(high_room, low_room) * 2;
+      uint32_t f;
+      if (val == 0) {
+        f = predicted;
+      } else {
+        flags_lo |= (1ull << lo) | (1ull << hi);  // lo, hi < i <= 64
+        if (i < 64) flags_lo |= 1ull << i; else flag_64 = 1;
+        if (val >= room)
+          f = high_room > low_room ? val - low_room + predicted : predicted - val + high_room - 1;
+        else
+          f = (val & 1u) ? predicted - (val + 1) / 2 : predicted + val / 2;
+      }
+      s_fy[i][t] = f;
     }
-    fy[i] = f;
-  }
-  if (bad) {
-    raise_status(status, VSYN_ST_FLOOR_RANGE, p);
-    for (uint32_t i = 0; i < posts; ++i) out[i] = 0x8000;  // flat zero curve, all flagged: harmless
-    return;
-  }
-  for (uint32_t i = 0; i < posts; ++i) {
-    uint32_t v = fy[i] * mult;  // hpp:573,578
-    if (v > 0x7FFFu || fy[i] > 0x7FFFu) v = 0x7FFFu;  // wrapped / absurd amplitude: renders >= 256 -> FLOOR_VALUE later
-    uint32_t fl = i < 64 ? (uint32_t)((flags_lo >> i) & 1ull) : flag_64;
-    out[i] = (uint16_t)(v | (fl << 15));
+    if (bad) {
+      raise_status(status, VSYN_ST_FLOOR_RANGE, p);
+      for (uint32_t i = 0; i < posts; ++i) out[i] = 0x8000;  // flat zero curve, all flagged: harmless
+      continue;
+    }
+    uint2* out8 = (uint2*)out;
+    for (uint32_t j = 0; j * 4 < posts; ++j) {  // 8-byte stores, 4 posts each (row stride is a multiple of 4)
+      uint32_t w[4];
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        const uint32_t i = 4 * j + e;
+        const uint32_t f = i < posts ? s_fy[i < VSYN_MAX_POSTS ? i : 0][t] : 0u;
+        uint32_t v = f * mult;  // hpp:573,578
+        if (v > 0x7FFFu || f > 0x7FFFu) v = 0x7FFFu;  // wrapped / absurd amplitude: renders >= 256 -> FLOOR_VALUE later
+        const uint32_t fl = i < 64 ? (uint32_t)((flags_lo >> i) & 1ull) : (i == 64 ? flag_64 : 0u);
+        w[e] = i < posts ? (v | (fl << 15)) : 0u;
+      }
+      out8[j] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+    }
   }
 }
 
@@ -315,17 +382,12 @@ __device__ __forceinline__ uint32_t floor1_curve_at(const FloorConst* fc, const 
 // K2 (staged)  inverse coupling (hpp:1213-1241) + floor product (hpp:1243-1255): one thread per bin,
 // all channels of the bin handled by the same thread (couplings chain across channels), in place in `env`.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void inverse_couple(float& m, float& a) {  // hpp:1220-1239
-  float m2 = m, a2 = a;
-  if (m > 0.f) {
-    if (a > 0.f) a2 = m - a;
-    else { a2 = m; m2 = m + a; }
-  } else {
-    if (a > 0.f) a2 = m + a;
-    else { a2 = m; m2 = m - a; }
-  }
-  m = m2;
-  a = a2;
+__device__ __forceinline__ void inverse_couple(float& m, float& a) {  // hpp:1220-1239 as selects (see couple2)
+  const float d = m > 0.f ? a : -a;
+  const float x = m - d, y = m + d;
+  const bool ap = a > 0.f;
+  a = ap ? x : m;
+  m = ap ? m : y;
 }
 
 __global__ void __launch_bounds__(256)
