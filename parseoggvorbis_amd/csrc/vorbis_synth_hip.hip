@@ -455,7 +455,7 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct);
   const bool force_staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !h->fused_ok;
   const uint32_t R = force_staged ? std::min<uint32_t>(max_seg_packets, 1024u)
-                                  : fused_pick_run_len(h->fused, S, max_seg_packets, h->num_cus);
+                                  : fused_pick_run_len(h->fused, S, C, max_seg_packets, h->num_cus);
 
   HIPCHK(h->ws_info.ensure(P));
   HIPCHK(h->ws_seg.ensure(S));
@@ -528,7 +528,7 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     a.R = R;
     a.fused_ok = 1;
     HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
-    hipError_t e = fused_launch(H, a, max_seg_packets, s);
+    hipError_t e = fused_launch(H, h->fused, a, max_seg_packets, s);
     if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
     HIPCHK(profile_end(h, s));
     HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));

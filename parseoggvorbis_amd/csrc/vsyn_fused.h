@@ -22,7 +22,12 @@
 
 #include "vsyn_device.h"
 
+#ifndef FUSED_WAVES
 #define FUSED_WAVES 8     // waves per workgroup (tables are shared per workgroup)
+#endif
+#ifndef FUSED_MIN_WAVES_PER_SIMD
+#define FUSED_MIN_WAVES_PER_SIMD 4
+#endif
 #define FUSED_XSLOTS 576  // float2 slots of the per-wave exchange image: 8 rows x 72 (>= 8 x 65)
 
 // Read-only LDS image of the fused kernel, built once per handle on the host in exactly the order the lanes read
@@ -34,13 +39,14 @@ struct FusedLdsImage {
   float2 tw2[8][8];       // W64^(c * a), c = lane & 7 (row 0 unused)
   float win[2][2][8][64]; // [prev/next flag][0: at s, 1: at 1023-s][k][lane]: left half of the long window at the
                           // output sample s of point m; the right half for next flag f is its mirror (hpp:850-859)
-  float invdb[256];       // Vorbis I 10.1 (hpp:588)
+  float invdb[260];       // Vorbis I 10.1 (hpp:588); [255] == 1.0f, extra [256] == 0.0f (see floor product)
 };
 
 struct FusedTables {
   uint8_t* d_binseg = nullptr;  // [num_floors][bs1/2]: sorted-post interval containing bin x
   FusedLdsImage* d_lds = nullptr;
   int waves_per_cu = 12;
+  int coupling_mode = 0;
 };
 
 struct FusedArgs {
@@ -57,7 +63,7 @@ struct FusedArgs {
   float* carry;
   DevStatus* status;
   uint64_t plane_stride;
-  uint32_t S, R, fused_ok;
+  uint32_t S, R, fused_ok, coupling_mode;
 };
 
 __device__ __forceinline__ float2 f2(float x, float y) { return make_float2(x, y); }
@@ -113,121 +119,136 @@ __device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__
 
 // hpp:1220-1239, branch-free (selects only; same comparisons, same single add/sub per output, so bit-identical):
 //   d = m > 0 ? a : -a;   a > 0 ? (M, A) = (m, m - d) : (M, A) = (m + d, m)
-__device__ __forceinline__ void couple2(float& m, float& a) {
+__device__ __forceinline__ float couple_mag(float m, float a) {  // new magnitude-channel value
   const float d = m > 0.f ? a : -a;
-  const float x = m - d, y = m + d;
-  const bool ap = a > 0.f;
-  a = ap ? x : m;
-  m = ap ? m : y;
+  return a > 0.f ? m : m + d;
+}
+__device__ __forceinline__ float couple_ang(float m, float a) {  // new angle-channel value
+  const float d = m > 0.f ? a : -a;
+  return a > 0.f ? m - d : m;
 }
 
-template <int C>
-__global__ void __launch_bounds__(FUSED_WAVES * 64, 4) vsyn_fused_long_kernel(const FusedArgs A) {
+// The whole per-wave job: the run [qa, qb) of segment g, output channel c.
+// ROLE: 0 channel c is not coupled; 1 c is the magnitude channel of the (single) coupling step, `pc` its angle
+// partner; 2 c is the angle channel, `pc` the magnitude partner. A coupled wave loads both channels' residue and
+// keeps only its own side of hpp:1219-1240 (5 VALU per bin instead of 7 for both).
+template <int ROLE>
+__device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, float4* __restrict__ seg,
+                                          const uint32_t lane0, const uint32_t g, const vsyn_segment sg, const SegInfo si,
+                                          const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c, const uint32_t pc) {
   constexpr uint32_t M = 1024;
-  __shared__ FusedLdsImage s_t;
-  __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
-  __shared__ float4 s_seg[FUSED_WAVES][C][64];
-
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
-  {
-    const uint4* src = (const uint4*)A.lds_image;
-    uint4* dst = (uint4*)&s_t;
-    for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
-  }
-  __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
-
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t g = blockIdx.y;
-  if (g >= A.S) return;
-  const vsyn_segment sg = A.segs[g];
-  const uint32_t run = blockIdx.x * FUSED_WAVES + wave;
   const uint32_t num = sg.num_packets;
-  const uint32_t qa = run * A.R;
-  if (qa >= num) return;
-  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // the layout kernel flagged it
-  const uint32_t qb = min(num, qa + A.R);
-  const SegInfo si = A.sinfo[g];
-  const vsyn_packet* spk = A.packets + sg.first_packet;
-  if (!run_is_fast(H, spk, qa, qb, si.has_carry ? si.carry_n : 0u, A.fused_ok)) return;  // staged list has it
 
-  const size_t carry_half = (size_t)H->max_streams * C * M;
-
-  float P[C][8];  // overlap carry of the run: -u_prev[511 - s] per point, unwindowed
+  float P[8];  // overlap carry of the run: -u_prev[511 - s] per point, unwindowed
 #pragma unroll
-  for (int c = 0; c < C; ++c)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) P[c][k] = 0.f;
+  for (int k = 0; k < 8; ++k) P[k] = 0.f;
   uint32_t prev_next_long = 1;
 
-  uint32_t bseg[C][4];
-  int bseg_floor[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    bseg_floor[c] = -1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bseg[c][j] = 0;
-  }
+  // lane constants of the floor in use (reloaded only when the floor changes, wave-uniform)
+  uint32_t bseg[4] = {0, 0, 0, 0};  // sorted-post interval of each of this lane's 16 bins, one byte each
+  uint32_t sidx = 0, xsl = 0;       // header index / x of sorted post `lane`
+  int cur_floor = -1;
+  uint32_t vrow = 0;
+  bool vrow_ok = false;
 
-  uint32_t lane_v = lane;
-  for (uint32_t q = qa ? qa - 1 : 0; q < qb; ++q) {
-    // launder the lane id once per packet: keeps the ~40 lane-derived LDS/global addresses from being hoisted
-    // out of the loop and pinned in VGPRs for its whole duration (recomputing them costs a few VALU ops)
+  const uint32_t q0 = qa ? qa - 1 : 0;
+  PktInfo pi = A.info[sg.first_packet + q0];
+  float2 raw[ROLE == 0 ? 1 : 2][8];  // [0] own channel, [1] coupling partner
+  {
+    const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M);
+    const float2* psrc = (const float2*)(A.residue + pi.res_off + (size_t)pc * M);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) raw[0][t] = src[lane0 + 64 * t];
+    if (ROLE != 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) raw[1][t] = psrc[lane0 + 64 * t];
+    }
+  }
+  uint32_t lane_v = lane0;
+  for (uint32_t q = q0; q < qb; ++q) {
+    // launder the lane id once per packet: keeps the lane-derived LDS/global addresses from being hoisted out of
+    // the loop and pinned in VGPRs for its whole duration (recomputing them costs a few VALU ops)
     asm volatile("" : "+v"(lane_v));
     const uint32_t lane = lane_v;
     const uint32_t kappa = ((lane & 7u) << 3) | (lane >> 3);
-    float2* xb = s_x[wave];
     const uint32_t p = sg.first_packet + q;
-    const PktInfo pi = A.info[p];
-    const bool halo = q < qa;
+    const bool halo = q < qa, has_next = q + 1 < qb;
     const MapConst* mc = map_of(cb, pi.mapping);
+    const PktInfo pin = A.info[has_next ? p + 1 : p];  // scalar loads, one packet ahead (never a struct select: that
+                                                       // would bounce through scratch memory)
 
-    // ---- residue: r[c][t] = bins (2k, 2k+1), k = lane + 64 t -------------------------------------------
-    float2 r[C][8];
+    // ---- residue: bins (2k, 2k+1), k = lane + 64 t (requested one packet ahead, see below); inverse coupling keeps
+    //      this wave's side only (hpp:1213-1241) ----------------------------------------------------------------
+    float2 r[8];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) r[c][t] = src[lane + 64 * t];
+    for (int t = 0; t < 8; ++t) {
+      if (ROLE == 0) r[t] = raw[0][t];
+      else if (ROLE == 1) r[t] = f2(couple_mag(raw[0][t].x, raw[1][t].x), couple_mag(raw[0][t].y, raw[1][t].y));
+      else r[t] = f2(couple_ang(raw[1][t].x, raw[0][t].x), couple_ang(raw[1][t].y, raw[0][t].y));
     }
+    // `raw` is dead: request packet q+1 now, so that its 4-8 KiB stay in flight behind this packet's floor product,
+    // FFT and overlap (memory-level parallelism is what bounds this kernel, not occupancy). Unconditional on purpose:
+    // on a run's last packet the current block is re-read (cache-resident, 1/R of the loads) — a `has_next` guard lets
+    // the compiler fold these loads back into the loop header.
+    {
+      const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * M);
+      const float2* psrc = (const float2*)(A.residue + pin.res_off + (size_t)pc * M);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) raw[0][t] = src[lane + 64 * t];
+      if (ROLE != 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) raw[1][t] = psrc[lane + 64 * t];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- floor-1 step 2 set-up: one table entry per sorted-post interval (hpp:563-584) ---------------------
     bool floor_bad = false;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      if (!((pi.own >> c) & 1u)) continue;
+    if (!((pi.own >> c) & 1u)) {
+      // no curve of its own: one constant entry. Not used at all -> index 255 (table value exactly 1.0f, x*1 == x);
+      // used through the coupling propagate -> index 256 (0.0f: floor_outputs stays zero, hpp:1159,1176-1179)
+      float4 e;
+      e.x = 0.f;
+      e.y = 0.f;
+      e.z = 0.f;
+      e.w = ((pi.used >> c) & 1u) ? 256.f : 255.f;
+      seg[lane] = e;
+    } else {
       const uint32_t f = mc->chfloor[c];
       const FloorConst* fc = floor_of(cb, f);
-      if (bseg_floor[c] != (int)f) {  // wave-uniform, changes only when the mapping changes
+      const uint16_t* row = A.fy + ((size_t)p * C + c) * H->ys_stride;
+      uint32_t v = vrow;
+      if (cur_floor != (int)f) {  // wave-uniform, changes only when the mapping changes
         const uint8_t* bs = A.binseg + (size_t)f * M;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));
-          if (t & 1) bseg[c][t >> 1] |= two << 16; else bseg[c][t >> 1] = two;
+          if (t & 1) bseg[t >> 1] |= two << 16; else bseg[t >> 1] = two;
         }
-        bseg_floor[c] = (int)f;
+        const bool in = lane < fc->posts;
+        sidx = in ? fc->sorted_idx[lane] : 0u;
+        xsl = in ? fc->xs_sorted[lane] : 0u;
+        cur_floor = (int)f;
+        v = row[sidx];
+      } else if (!vrow_ok) {
+        v = row[sidx];
       }
-      const uint32_t posts = fc->posts;
-      const uint16_t* row = A.fy + ((size_t)p * C + c) * H->ys_stride;
-      uint32_t v = 0, xs = 0;
-      if (lane < posts) {
-        v = row[fc->sorted_idx[lane]];
-        xs = fc->xs_sorted[lane];
-      }
+      if (lane >= fc->posts) v = 0;
       const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
       const uint64_t below = mask & ((2ull << lane) - 1ull);  // flagged positions <= lane (bit 0 always set)
       const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
       const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
       const bool has_hi = above != 0ull;
       const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
-      const uint32_t packed = (xs << 16) | (v & 0x7FFFu);
+      const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
       const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
       const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
       // segment (x0,y0)-(x1,y1) in slope/intercept form: curve(x) = y0 + sgn * floor(x*A + B) with
       // A = |dy|/adx, B = (0.5 - |dy| x0)/adx  ==  y0 +- (|dy| (x - x0)) / adx  in integers (Utils.hpp:122-137);
       // the +0.5/adx guard band (>= 4.9e-4) dwarfs the f32 rounding of x*A + B (<= 6e-5 for x < 1024), DESIGN.md
-      floor_bad |= (v & 0x7FFFu) > 255u;  // a flagged or unflagged post above 255 can only render >= 256 (hpp:587)
+      floor_bad = (v & 0x7FFFu) > 255u;  // a post above 255 can only render >= 256 (hpp:587)
       const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
       const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
       const float inv = has_hi ? 1.0f / (x1 - x0) : 0.f;
@@ -237,119 +258,126 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, 4) vsyn_fused_long_kernel(co
       e.y = __builtin_fmaf(-ady, x0, 0.5f) * inv;
       e.z = y1 >= y0 ? 1.f : -1.f;
       e.w = y0;
-      s_seg[wave][c][lane] = e;
+      seg[lane] = e;
     }
+    // coded posts of packet q+1, one packet ahead (valid if the floor does not change)
+    vrow_ok = has_next && pin.mapping == pi.mapping && cur_floor >= 0;
+    vrow = (A.fy + ((size_t)(has_next ? p + 1 : p) * C + c) * H->ys_stride)[sidx];
 
-    // ---- inverse coupling (hpp:1213-1241): at most one (magnitude, angle) step in this kernel ----------------
-    if (C == 2 && mc->ncoup) {
-      if (mc->coup[0] == 0) {  // magnitude = channel 0 (one wave-uniform branch, not one per bin)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          couple2(r[0][t].x, r[C - 1][t].x);
-          couple2(r[0][t].y, r[C - 1][t].y);
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          couple2(r[C - 1][t].x, r[0][t].x);
-          couple2(r[C - 1][t].y, r[0][t].y);
-        }
-      }
-    }
-
-    const uint32_t emit = halo ? 0u : pi.emit;
-    const float (*TL)[8][64] = s_t.win[pi.widx & 1u];    // this block's left-half window
-    const float (*TR)[8][64] = s_t.win[prev_next_long];  // previous block's right-half window, mirrored
-    const uint32_t cur_next_long = (pi.widx >> 1) & 1u;
+    // ---- floor curve at this lane's 16 bins + product (hpp:585-589, 1243-1255) -----------------------------
+    // (a channel without a curve was given a constant x1.0 / x0.0 entry above: no branch here)
     const float xf0 = (float)(2u * lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float fl2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int b = 2 * t + e;
+        const uint32_t sidx_b = (bseg[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+        const float4 sgm = seg[sidx_b];
+        const float qf = floorf(__builtin_fmaf(xf0 + (float)(128 * t + e), sgm.x, sgm.y));
+        fl2[e] = T.invdb[(uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w)];  // index 0..255 between two posts <= 255
+      }
+      r[t] = f2(r[t].x * fl2[0], r[t].y * fl2[1]);
+    }
 
+    // ---- IMDCT: mirror exchange, pre-rotation, FFT-512, post-rotation -------------------------------------
+    float2 z[8];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      // ---- floor curve at this lane's 16 bins + product (hpp:585-589, 1243-1255) ---------------------------
-      if ((pi.used >> c) & 1u) {
-        if (!((pi.own >> c) & 1u)) {  // propagated from the coupled channel: floor_outputs is all zero
+    for (int t = 0; t < 8; ++t) {
+      const float im = __shfl(r[7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
+      z[t] = cmulf(f2(r[t].x, im), T.pre[t][lane]);
+    }
+    fft512_wave(z, xb, &T, lane);
 #pragma unroll
-          for (int t = 0; t < 8; ++t) r[c][t] = f2(r[c][t].x * 0.f, r[c][t].y * 0.f);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            float fl2[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const int b = 2 * t + e;
-              const uint32_t sidx = (bseg[c][b >> 2] >> (8 * (b & 3))) & 0xFFu;
-              const float4 sgm = s_seg[wave][c][sidx];
-              const float qf = floorf(__builtin_fmaf(xf0 + (float)(128 * t + e), sgm.x, sgm.y));
-              fl2[e] = s_t.invdb[(uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w)];  // in 0..255: between two posts <= 255
-            }
-            r[c][t] = f2(r[c][t].x * fl2[0], r[c][t].y * fl2[1]);
-            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep the LDS gathers from being hoisted en bloc
-          }
-        }
-      }
+    for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post[k][lane]);
 
-      // ---- IMDCT: mirror exchange, pre-rotation, FFT-512, post-rotation -----------------------------------
-      float2 z[8];
+    // ---- window + overlap-add + PCM store (hpp:1008-1059) --------------------------------------------------
+    // point m = kappa + 64k gives samples s and 1023-s of this packet's output:
+    //   out[s]      = fl(P*wr(s))      + fl( cc*wl(s))        cc =  u_cur[512+s]
+    //   out[1023-s] = fl(P*wr(1023-s)) + fl(-cc*wl(1023-s))   P  = -u_prev[511-s]
+    // Handled as four point pairs (k, 7-k): each pair yields the contiguous samples (s, s+1) and (1022-s, 1023-s)
+    // after one exchange with the mirror lane. Computed for halo / first packets too (emit == 0): only the stores are
+    // guarded. P is zero until the run has seen a block; 0*w + x == x exactly as in `buf = 0; buf += x`.
+    const uint32_t emit = halo ? 0u : pi.emit;
+    const float (*TL)[8][64] = T.win[pi.widx & 1u];    // this block's left-half window
+    const float (*TR)[8][64] = T.win[prev_next_long];  // previous block's right-half window, mirrored
+    const uint32_t cur_next_long = (pi.widx >> 1) & 1u;
+    float* out = A.pcm + ((size_t)g * C + c) * A.plane_stride + pi.out_pos;
+    const bool fast_store = emit == M && (((uintptr_t)out & 7u) == 0);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float im = __shfl(r[c][7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
-        z[t] = cmulf(f2(r[c][t].x, im), s_t.pre[t][lane]);
+    for (int j = 0; j < 4; ++j) {
+      const int kh = 4 + j, kl = 3 - j;  // kh: even sample s = 2m-512 (own), kl: odd sample 511-2m (goes to the mirror lane)
+      const float cch = z[kh].x, ccl = -z[kl].y;
+      const float oh_s = P[kh] * TR[1][kh][lane] + cch * TL[0][kh][lane];
+      const float oh_m = P[kh] * TR[0][kh][lane] + (-cch) * TL[1][kh][lane];
+      const float ol_s = P[kl] * TR[1][kl][lane] + ccl * TL[0][kl][lane];
+      const float ol_m = P[kl] * TR[0][kl][lane] + (-ccl) * TL[1][kl][lane];
+      P[kh] = z[kh].y;
+      P[kl] = -z[kl].x;
+      // partner point 511 - m of (this lane, kh) is (mirror lane, slot kl): it yields samples s+1 and 1022-s
+      const float n_s = __shfl(ol_s, 63 - (int)lane);
+      const float n_m = __shfl(ol_m, 63 - (int)lane);
+      const uint32_t s = 2u * (kappa + 64u * kh) - 512u;
+      if (fast_store) {
+        *(float2*)(out + s) = f2(oh_s, n_s);
+        *(float2*)(out + 1022u - s) = f2(n_m, oh_m);
+      } else if (emit) {
+        if (s < emit) out[s] = oh_s;
+        if (s + 1u < emit) out[s + 1u] = n_s;
+        if (1022u - s < emit) out[1022u - s] = n_m;
+        if (1023u - s < emit) out[1023u - s] = oh_m;
       }
-      fft512_wave(z, xb, &s_t, lane);
+    }
+    if (q == num - 1) {  // stream carry for the next submit: windowed right half, natural order
+      const size_t carry_half = (size_t)H->max_streams * C * M;
+      float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * M;
+      const float (*TN)[8][64] = T.win[cur_next_long];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], s_t.post[k][lane]);
-
-      // ---- window + overlap-add + PCM store (hpp:1008-1059) ------------------------------------------------
-      // point m = kappa + 64k gives samples s and 1023-s of this packet's output:
-      //   out[s]      = fl(P*wr(s))      + fl( cc*wl(s))        cc =  u_cur[512+s]
-      //   out[1023-s] = fl(P*wr(1023-s)) + fl(-cc*wl(1023-s))   P  = -u_prev[511-s]
-      float o_s[8], o_m[8];
-      if (emit) {  // P is zero until the run has seen a block, and 0*w + x == x exactly as in `buf = 0; buf += x`
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float cc = k >= 4 ? z[k].x : -z[k].y;
-          const float tp_s = P[c][k] * TR[1][k][lane], tp_m = P[c][k] * TR[0][k][lane];
-          o_s[k] = tp_s + cc * TL[0][k][lane];
-          o_m[k] = tp_m + (-cc) * TL[1][k][lane];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) P[c][k] = k >= 4 ? z[k].y : -z[k].x;
-      if (emit) {
-        float* out = A.pcm + ((size_t)g * C + c) * A.plane_stride + pi.out_pos;
-        const bool fast_store = emit == M && (((uintptr_t)out & 7u) == 0);
-#pragma unroll
-        for (int k = 4; k < 8; ++k) {
-          // partner point 511 - m sits in the mirror lane, slot 7-k, and yields samples s+1 and 1022-s
-          const float n_s = __shfl(o_s[7 - k], 63 - (int)lane);
-          const float n_m = __shfl(o_m[7 - k], 63 - (int)lane);
-          const uint32_t s = 2u * (kappa + 64u * k) - 512u;
-          if (fast_store) {
-            *(float2*)(out + s) = f2(o_s[k], n_s);
-            *(float2*)(out + 1022u - s) = f2(n_m, o_m[k]);
-          } else {
-            if (s < emit) out[s] = o_s[k];
-            if (s + 1u < emit) out[s + 1u] = n_s;
-            if (1022u - s < emit) out[1022u - s] = n_m;
-            if (1023u - s < emit) out[1023u - s] = o_m[k];
-          }
-        }
-      }
-      if (q == num - 1) {  // stream carry for the next submit: windowed right half, natural order
-        float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * M;
-        const float (*TN)[8][64] = s_t.win[cur_next_long];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t m = kappa + 64u * k;
-          const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
-          cout[s] = P[c][k] * TN[1][k][lane];
-          cout[1023u - s] = P[c][k] * TN[0][k][lane];
-        }
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t m = kappa + 64u * k;
+        const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
+        cout[s] = P[k] * TN[1][k][lane];
+        cout[1023u - s] = P[k] * TN[0][k][lane];
       }
     }
     if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
     prev_next_long = cur_next_long;
+    pi = pin;
   }
+}
+
+// grid: x = groups of FUSED_WAVES runs, y = segment, z = channel
+__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_long_kernel(const FusedArgs A) {
+  __shared__ FusedLdsImage s_t;
+  __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
+  __shared__ float4 s_seg[FUSED_WAVES][64];
+  {
+    const uint4* src = (const uint4*)A.lds_image;
+    uint4* dst = (uint4*)&s_t;
+    for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
+  }
+  __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
+
+  const ConstHeader* H = hdr_of(A.cb);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = blockIdx.y, c = blockIdx.z, C = H->channels;
+  if (g >= A.S) return;
+  const vsyn_segment sg = A.segs[g];
+  const uint32_t run = blockIdx.x * FUSED_WAVES + wave;
+  const uint32_t qa = run * A.R;
+  if (qa >= sg.num_packets) return;
+  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // the layout kernel flagged it
+  const uint32_t qb = min(sg.num_packets, qa + A.R);
+  const SegInfo si = A.sinfo[g];
+  if (!run_is_fast(H, A.packets + sg.first_packet, qa, qb, si.has_carry ? si.carry_n : 0u, A.fused_ok)) return;  // staged list has it
+
+  // coupling structure is fixed per stream setup for the long-block mappings (fused_coupling_mode): channel roles
+  const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
+  if (A.coupling_mode == 0 || C < 2) fused_run<0>(A, s_t, s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, c);
+  else if (c == mag) fused_run<1>(A, s_t, s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, ang);
+  else fused_run<2>(A, s_t, s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, mag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -359,15 +387,28 @@ static inline bool fused_supported(const ConstHeader& H) {
   return H.bs[1] == 2048 && H.bs[0] <= 2048 && H.channels <= 2;
 }
 
+// coupling structure shared by every mapping that a long-block mode can select: 0 none, 1 (mag 0, ang 1), 2 (mag 1, ang 0);
+// -1 if the long-mode mappings disagree or chain several steps (those streams take the staged kernels)
+static inline int fused_coupling_mode(const ConstHeader& H, const uint8_t* host_const) {
+  const MapConst* mp = (const MapConst*)(host_const + H.off_map);
+  int mode = -2;
+  for (uint32_t k = 0; k < H.num_modes; ++k) {
+    if (!H.mode_blockflag[k]) continue;
+    const MapConst& m = mp[H.mode_mapping[k]];
+    if (m.ncoup > 1) return -1;
+    const int cur = m.ncoup == 0 ? 0 : (m.coup[0] == 0 ? 1 : 2);
+    if (mode == -2) mode = cur;
+    else if (mode != cur) return -1;
+  }
+  return mode == -2 ? 0 : mode;
+}
+
 static inline bool fused_setup_ok(const ConstHeader& H, const uint8_t* host_const) {
   if (!fused_supported(H)) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
   for (uint32_t f = 0; f < H.num_floors; ++f)
     if (fl[f].posts > 64) return false;  // one ballot covers the sorted posts
-  const MapConst* mp = (const MapConst*)(host_const + H.off_map);
-  for (uint32_t m = 0; m < H.num_mappings; ++m)
-    if (mp[m].ncoup > 1) return false;
-  return true;
+  return fused_coupling_mode(H, host_const) >= 0;
 }
 
 static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t* host_const, FusedTables* ft) {
@@ -409,14 +450,15 @@ static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t
     }
     for (uint32_t a = 0; a < 8; ++a)
       for (uint32_t c = 0; c < 8; ++c) im.tw2[a][c] = tw[(8 * c * a) & 511u];
-    memcpy(im.invdb, host_const + H.off_invdb, sizeof(im.invdb));
+    memcpy(im.invdb, host_const + H.off_invdb, 256 * sizeof(float));
     e = hipMalloc((void**)&ft->d_lds, sizeof(FusedLdsImage));
     if (e != hipSuccess) return e;
     e = hipMemcpy(ft->d_lds, &im, sizeof(FusedLdsImage), hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
   }
+  ft->coupling_mode = fused_coupling_mode(H, host_const);
   int blocks = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vsyn_fused_long_kernel<2>, FUSED_WAVES * 64, 0) == hipSuccess && blocks > 0)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vsyn_fused_long_kernel, FUSED_WAVES * 64, 0) == hipSuccess && blocks > 0)
     ft->waves_per_cu = blocks * FUSED_WAVES;
   return hipSuccess;
 }
@@ -432,20 +474,22 @@ static inline const char* fused_kernel_name(const ConstHeader&) { return "vsyn_f
 static inline const char* fused_imdct_kernel_name(uint32_t) { return "vsyn_imdct_plain_kernel"; }
 
 // run length: as few runs as fill the chip once (halo overhead is 1/R), never below 4
-static inline uint32_t fused_pick_run_len(const FusedTables& ft, uint32_t S, uint32_t max_seg_packets, int num_cus) {
+static inline uint32_t fused_pick_run_len(const FusedTables& ft, uint32_t S, uint32_t channels, uint32_t max_seg_packets, int num_cus) {
   const char* env = getenv("VSYN_RUN_LEN");
   if (env && atoi(env) > 0) return (uint32_t)atoi(env);
   const uint64_t slots = (uint64_t)num_cus * (uint64_t)ft.waves_per_cu;
   uint32_t R = 4;
-  while (R < max_seg_packets && (uint64_t)S * ((max_seg_packets + R - 1) / R) > slots) ++R;
+  while (R < max_seg_packets && (uint64_t)S * channels * ((max_seg_packets + R - 1) / R) > slots) ++R;
   return R;
 }
 
-static inline hipError_t fused_launch(const ConstHeader& H, const FusedArgs& a, uint32_t max_seg_packets, hipStream_t s) {
+static inline hipError_t fused_launch(const ConstHeader& H, const FusedTables& ft, FusedArgs a, uint32_t max_seg_packets, hipStream_t s) {
   const uint32_t runs = (max_seg_packets + a.R - 1) / a.R;
-  dim3 grid((runs + FUSED_WAVES - 1) / FUSED_WAVES, a.S);
-  if (H.channels == 1) vsyn_fused_long_kernel<1><<<grid, FUSED_WAVES * 64, 0, s>>>(a);
-  else vsyn_fused_long_kernel<2><<<grid, FUSED_WAVES * 64, 0, s>>>(a);
+  dim3 grid((runs + FUSED_WAVES - 1) / FUSED_WAVES, a.S, H.channels);
+  const char* xl = getenv("VSYN_EXTRA_LDS");  // experiment knob: extra dynamic LDS lowers the occupancy
+  const size_t dyn = xl ? (size_t)atoi(xl) : 0;
+  a.coupling_mode = (uint32_t)ft.coupling_mode;
+  vsyn_fused_long_kernel<<<grid, FUSED_WAVES * 64, dyn, s>>>(a);
   return hipGetLastError();
 }
 
