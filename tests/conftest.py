@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # PyTorch-ROCm bundles its own HIP runtime: it has to be the first one loaded into the test process
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

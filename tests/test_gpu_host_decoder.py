@@ -1,0 +1,82 @@
+"""GPU: the drop-in decoder end to end (BASELINE config 1 on the GPU box, where compare-debug-out.py and the
+reference cannot travel): ours_hip.bin decodes the reference's .ogg fixtures with --debug_out, and its dump is
+compared entry by entry with the committed dumps of the reference decoder — same grammar and tolerances as
+tests/compare-debug-out.py (ints exact, floats 1e-5; reference lines 90-151, 524-542)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.dump_reader import read_dump, split_packets
+from tests.workloads import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "parseoggvorbis_amd", "host")
+CLI = os.path.join(HOST, "ours_hip.bin")
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("batch", ["2048", "7"])
+@pytest.mark.parametrize("name", ["test.stereo44khz", "test.mono44khz"])
+def test_cli_dump_matches_reference(name, batch, tmp_path):
+    spec, b, z = load_golden(name)
+    dump = str(tmp_path / "d.bin")
+    env = dict(os.environ, PARSEOGGVORBIS_BATCH=batch)  # 7: many flushes, overlap carried between GPU batches
+    r = subprocess.run([CLI, "--in", os.path.join(GOLDEN, name + ".ogg"), "--debug_out", dump], capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    total = b["pcm"].shape[1]
+    assert "got eof. sample count: %d" % total in r.stdout and "\nok\n" in r.stdout
+    assert "Ogg total packets count: %d" % (len(b["packets"]) + 3) in r.stdout
+    header, entries = read_dump(dump)
+    Cn = spec.channels
+    assert int(header["decoder-num-channels"][0]) == Cn and int(header["decoder-sample-rate"][0]) == int(z["sample_rate"])
+    setup, packets, pcm = split_packets(entries, Cn)
+    # setup: (floor1_unpack multiplier, floor1_unpack xs)* finish_setup
+    assert [e[0] for e in setup] == ["floor1_unpack multiplier", "floor1_unpack xs"] * len(spec.floors)
+    for f, (mult, xs) in enumerate(spec.floors):
+        assert int(setup[2 * f][2][0]) == mult and list(setup[2 * f + 1][2]) == xs
+    assert len(packets) == len(b["packets"])
+    n_of = np.where(z["mode"] == 1, spec.blocksize1, spec.blocksize0)
+    off = np.concatenate([[0], np.cumsum(Cn * n_of // 2)])
+    pos = 0
+    for k, p in enumerate(packets):
+        assert p["abs_total_pos"] == pos and p["expected_ending_total_pos"] == int(b["packets"]["granule"][k])
+        pos += int(b["emit_len"][k])
+        n = int(n_of[k])
+        for c in range(Cn):
+            assert p["floor_number"][c] == int(z["floor_number"][k, c])
+            used = (int(b["packets"]["floor_used"][k]) >> c) & 1
+            assert (c in p["ys"]) == bool(used)
+            if used:
+                posts = len(spec.floors[p["floor_number"][c]][1])
+                assert np.array_equal(p["ys"][c], b["ys"][k, c, :posts])
+            res = b["residue"][off[k] + c * n // 2: off[k] + (c + 1) * n // 2]
+            assert np.array_equal(p["after_residue"][c].view(np.uint32), res.view(np.uint32))
+            key = "p%d_c%d_" % (k, c)
+            if key + "env" in z.files:
+                assert np.array_equal(p["after_envelope"][c].view(np.uint32), z[key + "env"].view(np.uint32))
+                assert np.abs(p["pcm_after_mdct"][c] - z[key + "mdct"]).max() < TOL
+                if used:
+                    assert np.array_equal(p["final_ys"][c], z[key + "final_ys"])
+                    assert np.array_equal(p["flag"][c], z[key + "flag"])
+            assert len(p["pcm_after_mdct"][c]) == n
+    for c in range(Cn):
+        assert len(pcm[c]) == total
+        assert np.abs(pcm[c] - b["pcm"][c]).max() < TOL
+
+
+def test_c_api_full_read(tmp_path):
+    lib = C.CDLL(os.path.join(HOST, "libparseoggvorbis_amd.so"))
+    lib.ogg_vorbis_full_read.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+    lib.ogg_vorbis_full_read_from_memory.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p)]
+    err = C.c_char_p()
+    assert lib.ogg_vorbis_full_read(os.path.join(GOLDEN, "test.mono44khz.ogg").encode(), C.byref(err)) == 0
+    data = open(os.path.join(GOLDEN, "test.stereo44khz.ogg"), "rb").read()
+    assert lib.ogg_vorbis_full_read_from_memory(data, len(data), C.byref(err)) == 0
+    assert lib.ogg_vorbis_full_read_from_memory(data[:5000], 5000, C.byref(err)) == 1  # torn page
+    assert b"check failed" in err.value
+    assert lib.ogg_vorbis_full_read(b"/nonexistent.ogg", None) == 1  # error_out may be NULL

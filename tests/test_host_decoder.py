@@ -1,0 +1,125 @@
+"""CPU-side tests of the host decoder (parseoggvorbis_amd/host): its entropy half against the reference decoder's
+hooks (tests/golden), the debug-hook dump format, the CLI contract and the "no CPU path" rule."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from parseoggvorbis_amd.binding import PACKET_DTYPE
+from tests.dump_reader import read_dump
+from tests.workloads import GOLDEN, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "parseoggvorbis_amd", "host")
+CLI = os.path.join(HOST, "ours_hip.bin")
+
+
+@pytest.fixture(scope="module")
+def built():
+    entry.build_hip()
+    entry.build_host()
+    return True
+
+
+@pytest.fixture(scope="module")
+def probe(built, tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("probe") / "host_entropy_dump")
+    csrc = os.path.join(ROOT, "parseoggvorbis_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-o", out, os.path.join(ROOT, "tests", "host_entropy_dump.cpp"),
+                    "-L" + HOST, "-lparseoggvorbis_amd", "-L" + csrc, "-lvorbis_synth_hip", "-Wl,-rpath," + HOST,
+                    "-Wl,-rpath," + csrc, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    return out
+
+
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("name", ["test.stereo44khz", "test.mono44khz"])
+def test_entropy_half_matches_reference_hooks(probe, name, tmp_path):
+    """mode / window flags / page granules / 'floor1 ys' / 'after_residue' of every packet == reference (exact)."""
+    if has_gpu():
+        pytest.skip("probe relies on the synthesis batch failing without a GPU")
+    spec, b, _ = load_golden(name)
+    out = str(tmp_path / "e.bin")
+    r = subprocess.run([probe, os.path.join(GOLDEN, name + ".ogg"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "no HIP device" in r.stdout  # the synthesis half refused to run on the CPU
+    raw = open(out, "rb").read()
+    P, Cn, stride, nres, bs0, bs1 = np.frombuffer(raw[:24], np.uint32)
+    assert (P, Cn, bs0, bs1) == (len(b["packets"]), spec.channels, spec.blocksize0, spec.blocksize1)
+    off = 24
+    pk = np.frombuffer(raw[off:off + 16 * P], PACKET_DTYPE)
+    off += 16 * P
+    ys = np.frombuffer(raw[off:off + 2 * P * Cn * stride], np.uint16).reshape(P, Cn, stride)
+    off += 2 * P * Cn * stride
+    res = np.frombuffer(raw[off:off + 4 * nres], np.float32)
+    for k in ("mode", "prev_long", "next_long", "floor_used", "granule"):
+        assert np.array_equal(pk[k], b["packets"][k]), k
+    assert np.array_equal(ys, b["ys"])
+    assert np.array_equal(res.view(np.uint32), b["residue"].view(np.uint32))
+
+
+def test_cli_contract(built, tmp_path):
+    """--help / bad args -> usage + exit 1 (reference: src/Callbacks.cpp:392-440); missing file -> exit 1."""
+    r = subprocess.run([CLI, "--help"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--in ogg_filename" in r.stdout
+    r = subprocess.run([CLI], capture_output=True, text=True)
+    assert r.returncode == 1 and "need to provide --in" in r.stderr
+    r = subprocess.run([CLI, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unexpected arg" in r.stderr
+    r = subprocess.run([CLI, "--in", str(tmp_path / "missing.ogg")], capture_output=True, text=True)
+    assert r.returncode == 1 and "check failed" in r.stderr  # "file:line: check failed: expr" convention
+
+
+def test_cli_fails_loudly_without_gpu(built):
+    if has_gpu():
+        pytest.skip("GPU present")
+    r = subprocess.run([CLI, "--in", os.path.join(GOLDEN, "test.stereo44khz.ogg")], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert "Setup: num codebooks: 38, num floors: 2, num mappings: 2, num modes: 2, num residues: 2" in r.stdout
+    assert "no HIP device" in r.stderr  # never a silent CPU fallback
+
+
+def test_corrupt_page_is_rejected(built, tmp_path):
+    data = bytearray(open(os.path.join(GOLDEN, "test.mono44khz.ogg"), "rb").read())
+    data[4000] ^= 0x55  # breaks a page CRC
+    p = tmp_path / "bad.ogg"
+    p.write_bytes(bytes(data))
+    r = subprocess.run([CLI, "--in", str(p)], capture_output=True, text=True)
+    assert r.returncode == 1 and "check failed: want_crc == crc" in r.stderr
+
+
+def test_hook_dump_format(built, tmp_path):
+    """The hook module writes the TLV layout the reference's harness parses (types, channel field, NULL payloads)."""
+    lib = C.CDLL(os.path.join(HOST, "libparseoggvorbis_amd.so"))
+    lib.push_data_float.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.push_data_u32.argtypes = lib.push_data_u8.argtypes = lib.push_data_i64.argtypes = lib.push_data_float.argtypes
+    lib.register_decoder_ref.argtypes = [C.c_void_p, C.c_char_p, C.c_long, C.c_int]
+    lib.unregister_decoder_ref.argtypes = [C.c_void_p]
+    lib.set_data_output_file.argtypes = [C.c_char_p]
+    lib.generic_itoa.restype = C.c_char_p
+    path = str(tmp_path / "d.bin")
+    ref = C.c_void_p(0x1234)
+    lib.set_data_output_file(path.encode())
+    lib.register_decoder_ref(ref, b"unit", 44100, 2)
+    f = np.arange(5, dtype=np.float32)
+    u = np.array([7, 8, 9], np.uint32)
+    g = np.array([-1], np.int64)
+    lib.push_data_u8(ref, b"finish_setup", -1, None, 0)
+    lib.push_data_float(ref, b"after_residue", 1, f.ctypes.data, 5)
+    lib.push_data_u32(ref, b"floor1 ys", -1, u.ctypes.data, 3)
+    lib.push_data_i64(ref, b"expected_ending_total_pos", -1, g.ctypes.data, 1)
+    lib.unregister_decoder_ref(ref)  # closes the file
+    header, entries = read_dump(path)
+    assert header["decoder-name"].tobytes() == b"unit" and int(header["decoder-sample-rate"][0]) == 44100
+    assert int(header["decoder-num-channels"][0]) == 2
+    assert [(n, c) for n, c, _, _ in entries] == [("finish_setup", -1), ("after_residue", 1), ("floor1 ys", -1),
+                                                   ("expected_ending_total_pos", -1)]
+    assert len(entries[0][2]) == 0 and np.array_equal(entries[1][2], f) and np.array_equal(entries[2][2], u)
+    assert entries[3][3] == 6 and int(entries[3][2][0]) == -1
+    assert lib.generic_itoa(5, 2, 8) == b"00000101"
