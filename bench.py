@@ -39,7 +39,7 @@ def build_batch(spec, streams, ppk, pattern, seed, device):
     C = spec.channels
     # coded floor rows: a pool of valid rows made on the host (the unwrap chain is serial per row), tiled on device
     pool_pk = 64 if pattern != "mixed" else 66
-    pool = synth_batch(spec, 4, pool_pk, pattern, seed=seed)
+    pool = synth_batch(spec, 4, pool_pk, pattern, seed=seed, roll=False)  # every pool stream shares one block pattern
     P = streams * ppk
     pk = np.zeros(P, PACKET_DTYPE)
     seg = np.zeros(streams, SEGMENT_DTYPE)
@@ -104,13 +104,9 @@ def main():
     from tests.workloads import fixture_like_spec
 
     # rank 0 owns the stream setup; ONE broadcast of the (tiny) setup block splits the job, then ranks are independent
-    spec = fixture_like_spec(2 if args.workload != "config2" else 1)
-    blob = np.array([spec.channels, spec.blocksize0, spec.blocksize1] + [len(spec.floors[0][1])] + spec.floors[0][1] +
-                    [len(spec.floors[1][1])] + spec.floors[1][1], np.int32)
-    if world > 1:
-        t = torch.from_numpy(blob).to(device) if rank == 0 else torch.zeros(len(blob), dtype=torch.int32, device=device)
-        dist.broadcast(t, 0)
-        assert np.array_equal(t.cpu().numpy(), blob)
+    from parseoggvorbis_amd import sharding
+    spec = fixture_like_spec(2 if args.workload != "config2" else 1) if rank == 0 else fixture_like_spec(1, 64, 64)
+    spec = sharding.broadcast_spec(spec, device, src=0)
 
     stream = torch.cuda.current_stream().cuda_stream
     flags = VSYN_SUBMIT_STAGED if args.staged else 0
@@ -169,15 +165,7 @@ def main():
     kern_ms, launches, kern_name = gpu.profile_read()
     gpu.profile(False)
 
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        cnt = torch.tensor([units], device=device, dtype=torch.int64)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_units = int(cnt.item())
-    else:
-        total_units = units
+    dt, total_units, _ = sharding.aggregate(dt, units, device)  # max clock over ranks, summed packet count
 
     # parity spot check against the CPU oracle on the first streams of this rank's batch (not timed)
     max_err, cpu = None, None
