@@ -119,6 +119,11 @@ __device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__
 
 // hpp:1220-1239, branch-free (selects only; same comparisons, same single add/sub per output, so bit-identical):
 //   d = m > 0 ? a : -a;   a > 0 ? (M, A) = (m, m - d) : (M, A) = (m + d, m)
+// Workgroup barrier for LDS hand-offs between waves that must NOT drain the vector-memory queue (the look-ahead residue
+// loads stay in flight across it): wait for this wave's LDS traffic only, then s_barrier. (__syncthreads() would add
+// vmcnt(0).)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float couple_mag(float m, float a) {  // new magnitude-channel value
   const float d = m > 0.f ? a : -a;
   return a > 0.f ? m : m + d;
@@ -133,7 +138,7 @@ __device__ __forceinline__ float couple_ang(float m, float a) {  // new angle-ch
 // partner; 2 c is the angle channel, `pc` the magnitude partner. A coupled wave loads both channels' residue and
 // keeps only its own side of hpp:1219-1240 (5 VALU per bin instead of 7 for both).
 template <int ROLE>
-__device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, float4* __restrict__ seg,
+__device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb, float4* __restrict__ seg,
                                           const uint32_t lane0, const uint32_t g, const vsyn_segment sg, const SegInfo si,
                                           const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c, const uint32_t pc) {
   constexpr uint32_t M = 1024;
@@ -155,19 +160,25 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 
   const uint32_t q0 = qa ? qa - 1 : 0;
   PktInfo pi = A.info[sg.first_packet + q0];
-  float2 raw[ROLE == 0 ? 1 : 2][8];  // [0] own channel, [1] coupling partner
+  float2 raw[8];  // own channel's residue, requested one packet ahead
   {
     const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M);
-    const float2* psrc = (const float2*)(A.residue + pi.res_off + (size_t)pc * M);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) raw[0][t] = src[lane0 + 64 * t];
-    if (ROLE != 0) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) raw[1][t] = psrc[lane0 + 64 * t];
-    }
+    for (int t = 0; t < 8; ++t) raw[t] = src[lane0 + 64 * t];
   }
   uint32_t lane_v = lane0;
-  for (uint32_t q = q0; q < qb; ++q) {
+  // Every wave of the workgroup runs exactly R+1 iterations with two s_barriers each. The two waves of a coupled channel
+  // pair (adjacent waves, same run) each load ONLY their own channel from HBM and hand it to the partner through their
+  // exchange image, which is idle at that point: loading both channels in both waves costs a second HBM fetch of the
+  // whole input (measured: concurrent misses on a line are not merged; FETCH_SIZE x2 = 1.10 GB vs 0.55 GB per launch).
+  // Waves with fewer packets idle through the remaining barriers.
+  for (uint32_t it = 0; it <= A.R; ++it) {
+    const uint32_t q = q0 + it;
+    if (q >= qb) {
+      lds_barrier();
+      lds_barrier();
+      continue;
+    }
     // launder the lane id once per packet: keeps the lane-derived LDS/global addresses from being hoisted out of
     // the loop and pinned in VGPRs for its whole duration (recomputing them costs a few VALU ops)
     asm volatile("" : "+v"(lane_v));
@@ -182,25 +193,30 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     // ---- residue: bins (2k, 2k+1), k = lane + 64 t (requested one packet ahead, see below); inverse coupling keeps
     //      this wave's side only (hpp:1213-1241) ----------------------------------------------------------------
     float2 r[8];
+    if (ROLE != 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
+    }
+    lds_barrier();  // B1: both channels of the pair are in LDS
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (ROLE == 0) r[t] = raw[0][t];
-      else if (ROLE == 1) r[t] = f2(couple_mag(raw[0][t].x, raw[1][t].x), couple_mag(raw[0][t].y, raw[1][t].y));
-      else r[t] = f2(couple_ang(raw[1][t].x, raw[0][t].x), couple_ang(raw[1][t].y, raw[0][t].y));
+      if (ROLE == 0) {
+        r[t] = raw[t];
+      } else {
+        const float2 oth = pxb[t * 64 + lane];
+        r[t] = ROLE == 1 ? f2(couple_mag(raw[t].x, oth.x), couple_mag(raw[t].y, oth.y))
+                         : f2(couple_ang(oth.x, raw[t].x), couple_ang(oth.y, raw[t].y));
+      }
     }
-    // `raw` is dead: request packet q+1 now, so that its 4-8 KiB stay in flight behind this packet's floor product,
-    // FFT and overlap (memory-level parallelism is what bounds this kernel, not occupancy). Unconditional on purpose:
-    // on a run's last packet the current block is re-read (cache-resident, 1/R of the loads) — a `has_next` guard lets
-    // the compiler fold these loads back into the loop header.
+    lds_barrier();  // B2: the partner has read this wave's image; it may be reused by the FFT below
+    // `raw` is dead: request packet q+1 now, so that its 4 KiB stay in flight behind this packet's floor product, FFT and
+    // overlap (memory-level parallelism bounded this kernel, not occupancy). Unconditional on purpose: on a run's last
+    // packet the current block is re-read (cache-resident, 1/R of the loads) — a `has_next` guard lets the compiler fold
+    // these loads back into the loop header.
     {
       const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * M);
-      const float2* psrc = (const float2*)(A.residue + pin.res_off + (size_t)pc * M);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) raw[0][t] = src[lane + 64 * t];
-      if (ROLE != 0) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) raw[1][t] = psrc[lane + 64 * t];
-      }
+      for (int t = 0; t < 8; ++t) raw[t] = src[lane + 64 * t];
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -347,7 +363,9 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   }
 }
 
-// grid: x = groups of FUSED_WAVES runs, y = segment, z = channel
+// grid: x = groups of FUSED_WAVES (run, channel) units — the channels of a run sit in adjacent waves of one workgroup so
+// that the partner-channel loads of a coupled pair hit L1/L2 instead of HBM —, y = segment
+static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a workgroup");
 __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_long_kernel(const FusedArgs A) {
   __shared__ FusedLdsImage s_t;
   __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
@@ -362,22 +380,30 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   const ConstHeader* H = hdr_of(A.cb);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t g = blockIdx.y, c = blockIdx.z, C = H->channels;
+  const uint32_t g = blockIdx.y, C = H->channels;
   if (g >= A.S) return;
   const vsyn_segment sg = A.segs[g];
-  const uint32_t run = blockIdx.x * FUSED_WAVES + wave;
+  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // whole workgroup: the layout kernel flagged the segment
+  const uint32_t unit = blockIdx.x * FUSED_WAVES + wave;
+  const uint32_t run = unit / C, c = unit % C;
   const uint32_t qa = run * A.R;
-  if (qa >= sg.num_packets) return;
-  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // the layout kernel flagged it
   const uint32_t qb = min(sg.num_packets, qa + A.R);
   const SegInfo si = A.sinfo[g];
-  if (!run_is_fast(H, A.packets + sg.first_packet, qa, qb, si.has_carry ? si.carry_n : 0u, A.fused_ok)) return;  // staged list has it
+  const bool active = qa < sg.num_packets &&
+                      run_is_fast(H, A.packets + sg.first_packet, qa, qb, si.has_carry ? si.carry_n : 0u, A.fused_ok);  // else: staged list
+  if (!active) {  // keep the workgroup's barrier count balanced
+    for (uint32_t it = 0; it <= A.R; ++it) {
+      lds_barrier();
+      lds_barrier();
+    }
+    return;
+  }
 
   // coupling structure is fixed per stream setup for the long-block mappings (fused_coupling_mode): channel roles
   const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
-  if (A.coupling_mode == 0 || C < 2) fused_run<0>(A, s_t, s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, c);
-  else if (c == mag) fused_run<1>(A, s_t, s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, ang);
-  else fused_run<2>(A, s_t, s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, mag);
+  if (A.coupling_mode == 0 || C < 2) fused_run<0>(A, s_t, s_x[wave], s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, c);
+  else if (c == mag) fused_run<1>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, ang);
+  else fused_run<2>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, mag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,8 +510,8 @@ static inline uint32_t fused_pick_run_len(const FusedTables& ft, uint32_t S, uin
 }
 
 static inline hipError_t fused_launch(const ConstHeader& H, const FusedTables& ft, FusedArgs a, uint32_t max_seg_packets, hipStream_t s) {
-  const uint32_t runs = (max_seg_packets + a.R - 1) / a.R;
-  dim3 grid((runs + FUSED_WAVES - 1) / FUSED_WAVES, a.S, H.channels);
+  const uint32_t units = ((max_seg_packets + a.R - 1) / a.R) * H.channels;
+  dim3 grid((units + FUSED_WAVES - 1) / FUSED_WAVES, a.S);
   const char* xl = getenv("VSYN_EXTRA_LDS");  // experiment knob: extra dynamic LDS lowers the occupancy
   const size_t dyn = xl ? (size_t)atoi(xl) : 0;
   a.coupling_mode = (uint32_t)ft.coupling_mode;
