@@ -131,6 +131,9 @@ typedef struct vsyn_handle vsyn_handle;
 
 /* submit flags */
 #define VSYN_SUBMIT_STAGED 1u         /* force the staged (tap-capable, any-shape) kernels instead of the fused one */
+#define VSYN_SUBMIT_INPUTS_READY 2u   /* vsyn_submit_device: packets/segments/ys are complete already (not produced by work still
+                                         pending on hip_stream). Lets the layout + floor-unwrap kernels of this submit overlap the
+                                         synthesis kernel of the previous one; results are identical either way. */
 
 const char* vsyn_version(void);
 int vsyn_abi_version(void);

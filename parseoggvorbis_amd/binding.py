@@ -17,6 +17,7 @@ VSYN_OK, VSYN_ERR_INVALID, VSYN_ERR_NO_DEVICE, VSYN_ERR_HIP, VSYN_ERR_STREAM = 0
 VSYN_ST_FLOOR_RANGE, VSYN_ST_FLOOR_VALUE, VSYN_ST_GRANULE, VSYN_ST_PLANE_OVERFLOW, VSYN_ST_BAD_MODE = 1, 2, 4, 8, 16
 VSYN_SEG_RESET = 1
 VSYN_SUBMIT_STAGED = 1
+VSYN_SUBMIT_INPUTS_READY = 2
 
 
 class Floor1(C.Structure):

@@ -96,15 +96,18 @@ struct vsyn_handle {
   bool fused_ok = false;
   int num_cus = 256;
   hipStream_t side = nullptr;          // the (usually empty) staged work list runs beside the fused kernel
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  uint32_t submit_parity = 0;
+  hipStream_t pre = nullptr;           // layout + floor unwrap of submit i+1 run beside the fused kernel of submit i
+  hipEvent_t ev_join = nullptr, ev_pre_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr};
+  bool main_done_valid[2] = {false, false};
+  uint32_t submit_count = 0;
   // workspace
-  DevBuf<uint32_t> ws_list;   // staged work list (+ its counter in slot 0 of ws_count)
-  DevBuf<uint32_t> ws_count;
-  DevBuf<PktInfo> ws_info;
-  DevBuf<SegInfo> ws_seg;
-  DevBuf<uint32_t> ws_segmap;
-  DevBuf<uint16_t> ws_fy;
+  // per-batch workspace, double buffered by submit parity so that consecutive submits can overlap
+  DevBuf<uint32_t> ws_list[2];  // staged work list
+  DevBuf<uint32_t> ws_count;    // its counters: a ring of 4 (the layout kernel of submit i clears the slot of submit i+1)
+  DevBuf<PktInfo> ws_info[2];
+  DevBuf<SegInfo> ws_seg[2];
+  DevBuf<uint32_t> ws_segmap[2];
+  DevBuf<uint16_t> ws_fy[2];
   DevBuf<float> ws_env, ws_blk;
   // host-submit staging
   DevBuf<vsyn_packet> st_pk;
@@ -329,8 +332,12 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   HC(hipMemcpy(h->d_status, &init, sizeof(init), hipMemcpyHostToDevice));
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HC(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  HC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HC(hipStreamCreateWithFlags(&h->pre, hipStreamNonBlocking));
   HC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  for (int b = 0; b < 2; ++b) {
+    HC(hipEventCreateWithFlags(&h->ev_pre_done[b], hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&h->ev_main_done[b], hipEventDisableTiming));
+  }
   HC(h->ws_count.ensure(4));
   HC(hipMemset(h->ws_count.p, 0, sizeof(uint32_t) * 4));
   h->fused_ok = fused_setup_ok(h->H, h->host_const.data());
@@ -349,14 +356,21 @@ void vsyn_destroy(vsyn_handle* h) {
   (void)hipDeviceSynchronize();
   fused_tables_destroy(&h->fused);
   if (h->side) (void)hipStreamDestroy(h->side);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->pre) (void)hipStreamDestroy(h->pre);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (int b = 0; b < 2; ++b) {
+    if (h->ev_pre_done[b]) (void)hipEventDestroy(h->ev_pre_done[b]);
+    if (h->ev_main_done[b]) (void)hipEventDestroy(h->ev_main_done[b]);
+  }
   if (h->d_const) (void)hipFree(h->d_const);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_carry) (void)hipFree(h->d_carry);
   if (h->d_status) (void)hipFree(h->d_status);
-  h->ws_list.release(); h->ws_count.release();
-  h->ws_info.release(); h->ws_seg.release(); h->ws_segmap.release(); h->ws_fy.release(); h->ws_env.release(); h->ws_blk.release();
+  h->ws_count.release();
+  for (int b = 0; b < 2; ++b) {
+    h->ws_list[b].release(); h->ws_info[b].release(); h->ws_seg[b].release(); h->ws_segmap[b].release(); h->ws_fy[b].release();
+  }
+  h->ws_env.release(); h->ws_blk.release();
   h->st_pk.release(); h->st_seg.release(); h->st_ys.release(); h->st_fy.release(); h->st_res.release(); h->st_pcm.release();
   h->st_env.release(); h->st_blk.release(); h->st_emit.release();
   for (auto& ev : h->events) {
@@ -457,36 +471,45 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   const uint32_t R = force_staged ? std::min<uint32_t>(max_seg_packets, 1024u)
                                   : fused_pick_run_len(h->fused, S, C, max_seg_packets, h->num_cus);
 
-  HIPCHK(h->ws_info.ensure(P));
-  HIPCHK(h->ws_seg.ensure(S));
-  HIPCHK(h->ws_segmap.ensure(P));
-  HIPCHK(h->ws_list.ensure(2 * (size_t)P + 64));
+  // Workspace of this submit (double buffered). With VSYN_SUBMIT_INPUTS_READY the pre-kernels (layout scan, floor
+  // unwrap: latency-bound, ~50 us) go to an internal stream and overlap the previous submit's synthesis kernel; they
+  // only wait until the submit before that has released this workspace half.
+  const uint32_t wb = h->submit_count & 1u;
+  uint32_t* cnt = h->ws_count.p + (h->submit_count & 3u);
+  uint32_t* cnt_next = h->ws_count.p + ((h->submit_count + 1u) & 3u);
+  ++h->submit_count;
+  HIPCHK(h->ws_info[wb].ensure(P));
+  HIPCHK(h->ws_seg[wb].ensure(S));
+  HIPCHK(h->ws_segmap[wb].ensure(P));
+  HIPCHK(h->ws_list[wb].ensure(2 * (size_t)P + 64));
   uint16_t* fy = taps && taps->floor_final ? taps->floor_final : nullptr;
   if (!fy) {
-    HIPCHK(h->ws_fy.ensure((size_t)P * C * H.ys_stride));
-    fy = h->ws_fy.p;
+    HIPCHK(h->ws_fy[wb].ensure((size_t)P * C * H.ys_stride));
+    fy = h->ws_fy[wb].p;
   }
+  PktInfo* info = h->ws_info[wb].p;
+  SegInfo* sinfo = h->ws_seg[wb].p;
+  uint32_t* segmap = h->ws_segmap[wb].p;
+  uint32_t* list = h->ws_list[wb].p;
 
-  uint32_t* cnt = h->ws_count.p + (h->submit_parity & 1u);
-  uint32_t* cnt_next = h->ws_count.p + ((h->submit_parity & 1u) ^ 1u);
-  h->submit_parity ^= 1u;
-  vsyn_layout_kernel<<<S, 256, 0, s>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, h->ws_info.p, h->ws_seg.p,
-                                       h->d_state, d_emit_len, h->d_status, R, force_staged ? 0u : 1u, h->ws_list.p, cnt,
-                                       cnt_next, h->ws_segmap.p);
+  const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged;
+  hipStream_t ps = overlap_pre ? h->pre : s;
+  if (h->main_done_valid[wb]) HIPCHK(hipStreamWaitEvent(ps, h->ev_main_done[wb], 0));
+  vsyn_layout_kernel<<<S, 256, 0, ps>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len,
+                                        h->d_status, R, force_staged ? 0u : 1u, list, cnt, cnt_next, segmap);
   {
     const uint32_t rows = P * C;
-    vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, s>>>(
-        h->d_const, P, nullptr, nullptr, h->ws_info.p, d_ys, fy, h->d_status);
+    vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,
+                                                                                                       d_ys, fy, h->d_status);
   }
+  HIPCHK(hipEventRecord(h->ev_pre_done[wb], ps));
+  if (ps != s) HIPCHK(hipStreamWaitEvent(s, h->ev_pre_done[wb], 0));
 
   // staged kernels walk the work list the layout kernel built: everything when forced, otherwise only the runs the
   // fused kernel declines (short / mixed blocks, carry-in). In fused mode they run on a forked side stream beside the
   // fused kernel (disjoint outputs) and exit at once when the list is empty.
   hipStream_t ss = force_staged ? s : h->side;
-  if (!force_staged) {
-    HIPCHK(hipEventRecord(h->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  }
+  if (!force_staged) HIPCHK(hipStreamWaitEvent(h->side, h->ev_pre_done[wb], 0));
   {
     const size_t bound = (size_t)P * C * (H.bs[1] / 2);  // residue floats upper bound (device-resident descriptors)
     float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
@@ -500,13 +523,11 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
       blk = h->ws_blk.p;
     }
     const uint32_t grid = force_staged ? std::min<uint32_t>(P * C, 256u * 32u) : 512u;
-    vsyn_spectrum_kernel<<<std::min<uint32_t>(grid, P), 256, 0, ss>>>(h->d_const, h->ws_list.p, cnt, h->ws_info.p, d_residue, fy, env,
-                                                                    h->d_status);
+    vsyn_spectrum_kernel<<<std::min<uint32_t>(grid, P), 256, 0, ss>>>(h->d_const, list, cnt, info, d_residue, fy, env, h->d_status);
     if (force_staged) HIPCHK(profile_begin(h, s, "vsyn_imdct_staged_kernel"));
-    vsyn_imdct_staged_kernel<<<grid, 256, (size_t)H.bs[1] * 4, ss>>>(h->d_const, h->ws_list.p, cnt, h->ws_info.p, env, blk);
+    vsyn_imdct_staged_kernel<<<grid, 256, (size_t)H.bs[1] * 4, ss>>>(h->d_const, list, cnt, info, env, blk);
     if (force_staged) HIPCHK(profile_end(h, s));
-    vsyn_overlap_kernel<<<grid, 256, 0, ss>>>(h->d_const, h->ws_list.p, cnt, h->ws_info.p, d_segments, h->ws_seg.p, h->ws_segmap.p, blk,
-                                             d_pcm, plane_stride, h->d_carry);
+    vsyn_overlap_kernel<<<grid, 256, 0, ss>>>(h->d_const, list, cnt, info, d_segments, sinfo, segmap, blk, d_pcm, plane_stride, h->d_carry);
   }
   if (!force_staged) {
     HIPCHK(hipEventRecord(h->ev_join, h->side));
@@ -516,8 +537,8 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     a.lds_image = h->fused.d_lds;
     a.packets = d_packets;
     a.segs = d_segments;
-    a.info = h->ws_info.p;
-    a.sinfo = h->ws_seg.p;
+    a.info = info;
+    a.sinfo = sinfo;
     a.residue = d_residue;
     a.fy = fy;
     a.pcm = d_pcm;
@@ -533,6 +554,8 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     HIPCHK(profile_end(h, s));
     HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   }
+  HIPCHK(hipEventRecord(h->ev_main_done[wb], s));
+  h->main_done_valid[wb] = true;
   HIPCHK(hipGetLastError());
   return VSYN_OK;
 }

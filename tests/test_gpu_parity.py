@@ -214,3 +214,32 @@ def test_imdct_only(n):
     for r in (0, count - 1):
         ob.oracle().orc_imdct_closed_form(n, ob.p(x[r]), ob.p(cf))
         assert np.abs(got[r] - cf).max() < TOL * max(1.0, peak)
+
+
+def test_device_resident_back_to_back_submits_overlap_safely():
+    """vsyn_submit_device with VSYN_SUBMIT_INPUTS_READY: consecutive submits overlap their pre-kernels with the previous
+    synthesis kernel on double-buffered workspaces. Different batches back to back, no sync in between, each == oracle."""
+    import torch
+    spec = fixture_like_spec(2)
+    S, ppk = 6, 40
+    gpu = binding.Synth(spec, max_streams=S)
+    orc = ob.OracleSynth(spec, S)
+    stream = torch.cuda.current_stream().cuda_stream
+    keep, outs = [], []
+    for i in range(5):
+        b = synth_batch(spec, S, ppk, "long" if i % 2 == 0 else "mixed", seed=100 + i)
+        d = dict(pk=torch.from_numpy(b["packets"].view(np.uint8)).cuda(), seg=torch.from_numpy(b["segments"].view(np.uint8)).cuda(),
+                 ys=torch.from_numpy(b["ys"].astype(np.int16)).cuda(), res=torch.from_numpy(b["residue"]).cuda(),
+                 pcm=torch.zeros((S, 2, b["plane_stride"]), device="cuda"), emit=torch.zeros(S * ppk, dtype=torch.int32, device="cuda"))
+        keep.append(d)
+        outs.append(b)
+    torch.cuda.synchronize()
+    for d, b in zip(keep, outs):
+        gpu.submit_device(S * ppk, d["pk"].data_ptr(), S, d["seg"].data_ptr(), ppk, d["ys"].data_ptr(), d["res"].data_ptr(),
+                          d["pcm"].data_ptr(), b["plane_stride"], d["emit"].data_ptr(), None, binding.VSYN_SUBMIT_INPUTS_READY, stream)
+    fl, bad = gpu.sync_status(stream)
+    assert fl == 0, (fl, bad)
+    for d, b in zip(keep, outs):
+        want = orc.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+        assert np.array_equal(d["emit"].cpu().numpy().astype(np.uint32), want["emit_len"])
+        assert np.abs(d["pcm"].cpu().numpy() - want["pcm"]).max() < TOL
