@@ -241,8 +241,9 @@ class Synth:
         if rc != VSYN_OK:
             raise VsynError(rc, (err.value or b"").decode())
 
-    def profile(self, on=True):
-        self.lib.vsyn_profile_enable(self.h, 1 if on else 0)
+    def profile(self, on=1):
+        """0/False off, 1/True long-run fused kernel, 2 mixed-block fused kernel."""
+        self.lib.vsyn_profile_enable(self.h, int(on))
 
     def profile_read(self):
         ms, n, name = C.c_double(), C.c_uint32(), C.c_char_p()

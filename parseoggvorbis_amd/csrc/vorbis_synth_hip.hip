@@ -94,6 +94,7 @@ struct vsyn_handle {
   DevStatus* d_status = nullptr;
   FusedTables fused{};
   bool fused_ok = false;
+  uint32_t fused_mask = 0;
   int num_cus = 256;
   hipStream_t side = nullptr;          // the (usually empty) staged work list runs beside the fused kernel
   hipStream_t pre = nullptr;           // layout + floor unwrap of submit i+1 run beside the fused kernel of submit i
@@ -108,6 +109,7 @@ struct vsyn_handle {
   DevBuf<SegInfo> ws_seg[2];
   DevBuf<uint32_t> ws_segmap[2];
   DevBuf<uint16_t> ws_fy[2];
+  DevBuf<uint8_t> ws_runcls[2];
   DevBuf<float> ws_env, ws_blk;
   // host-submit staging
   DevBuf<vsyn_packet> st_pk;
@@ -117,6 +119,7 @@ struct vsyn_handle {
   DevBuf<uint32_t> st_emit;
   // profiling
   bool profile = false;
+  int profile_which = 1;  // 1: long-run fused kernel, 2: mixed-block fused kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   const char* profile_kernel = "";
@@ -340,7 +343,8 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   }
   HC(h->ws_count.ensure(4));
   HC(hipMemset(h->ws_count.p, 0, sizeof(uint32_t) * 4));
-  h->fused_ok = fused_setup_ok(h->H, h->host_const.data());
+  h->fused_mask = fused_ok_mask(h->H, h->host_const.data());
+  h->fused_ok = h->fused_mask != 0;
   if ((e = fused_tables_create(h->H, h->host_const.data(), &h->fused)) != hipSuccess) {
     fail(err, VSYN_ERR_HIP, "fused table upload failed: %s", hipGetErrorString(e));
     return cleanup(VSYN_ERR_HIP);
@@ -368,7 +372,7 @@ void vsyn_destroy(vsyn_handle* h) {
   if (h->d_status) (void)hipFree(h->d_status);
   h->ws_count.release();
   for (int b = 0; b < 2; ++b) {
-    h->ws_list[b].release(); h->ws_info[b].release(); h->ws_seg[b].release(); h->ws_segmap[b].release(); h->ws_fy[b].release();
+    h->ws_list[b].release(); h->ws_info[b].release(); h->ws_seg[b].release(); h->ws_segmap[b].release(); h->ws_fy[b].release(); h->ws_runcls[b].release();
   }
   h->ws_env.release(); h->ws_blk.release();
   h->st_pk.release(); h->st_seg.release(); h->st_ys.release(); h->st_fy.release(); h->st_res.release(); h->st_pcm.release();
@@ -387,6 +391,7 @@ size_t vsyn_const_block_bytes(const vsyn_handle* h) { return h ? h->host_const.s
 int vsyn_profile_enable(vsyn_handle* h, int on) {
   if (!h) return VSYN_ERR_INVALID;
   h->profile = on != 0;
+  if (on == 1 || on == 2) h->profile_which = on;
   return VSYN_OK;
 }
 
@@ -487,6 +492,8 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     HIPCHK(h->ws_fy[wb].ensure((size_t)P * C * H.ys_stride));
     fy = h->ws_fy[wb].p;
   }
+  const uint32_t runs_per_seg = (max_seg_packets + R - 1) / R;
+  HIPCHK(h->ws_runcls[wb].ensure((size_t)S * runs_per_seg + 16));
   PktInfo* info = h->ws_info[wb].p;
   SegInfo* sinfo = h->ws_seg[wb].p;
   uint32_t* segmap = h->ws_segmap[wb].p;
@@ -496,7 +503,7 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   hipStream_t ps = overlap_pre ? h->pre : s;
   if (h->main_done_valid[wb]) HIPCHK(hipStreamWaitEvent(ps, h->ev_main_done[wb], 0));
   vsyn_layout_kernel<<<S, 256, 0, ps>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len,
-                                        h->d_status, R, force_staged ? 0u : 1u, list, cnt, cnt_next, segmap);
+                                        h->d_status, R, force_staged ? 0u : h->fused_mask, list, cnt, cnt_next, segmap, h->ws_runcls[wb].p, runs_per_seg);
   {
     const uint32_t rows = P * C;
     vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,
@@ -530,7 +537,6 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     vsyn_overlap_kernel<<<grid, 256, 0, ss>>>(h->d_const, list, cnt, info, d_segments, sinfo, segmap, blk, d_pcm, plane_stride, h->d_carry);
   }
   if (!force_staged) {
-    HIPCHK(hipEventRecord(h->ev_join, h->side));
     FusedArgs a;
     a.cb = h->d_const;
     a.binseg = h->fused.d_binseg;
@@ -539,6 +545,8 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     a.segs = d_segments;
     a.info = info;
     a.sinfo = sinfo;
+    a.run_cls = h->ws_runcls[wb].p;
+    a.runs_per_seg = runs_per_seg;
     a.residue = d_residue;
     a.fy = fy;
     a.pcm = d_pcm;
@@ -547,11 +555,22 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     a.plane_stride = plane_stride;
     a.S = S;
     a.R = R;
-    a.fused_ok = 1;
-    HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
+    a.fused_ok = h->fused_mask;
+    a.coupling_mode = (uint32_t)h->fused.coupling_mode;
+    HIPCHK(hipEventRecord(h->ev_join, h->side));
+    if (h->profile_which == 1) HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
     hipError_t e = fused_launch(H, h->fused, a, max_seg_packets, s);
     if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
-    HIPCHK(profile_end(h, s));
+    if (h->profile_which == 1) HIPCHK(profile_end(h, s));
+    if (h->fused_mask & 2u) {
+      // mixed-block runs: after the long-run kernel on the same stream, NOT beside it — the long kernel's grid is sized to
+      // fill the chip in exactly one round, and even idle co-scheduled workgroups push part of it into a second one
+      // (measured +20 %). Its workgroups leave at once when the batch has no such run.
+      if (h->profile_which == 2) HIPCHK(profile_begin(h, s, "vsyn_fused_mixed_kernel"));
+      e = fused_mixed_launch(H, h->fused, a, max_seg_packets, s);
+      if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused mixed launch failed: %s", hipGetErrorString(e));
+      if (h->profile_which == 2) HIPCHK(profile_end(h, s));
+    }
     HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   }
   HIPCHK(hipEventRecord(h->ev_main_done[wb], s));

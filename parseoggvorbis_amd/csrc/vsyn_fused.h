@@ -40,6 +40,11 @@ struct FusedLdsImage {
   float win[2][2][8][64]; // [prev/next flag][0: at s, 1: at 1023-s][k][lane]: left half of the long window at the
                           // output sample s of point m; the right half for next flag f is its mirror (hpp:850-859)
   float invdb[260];       // Vorbis I 10.1 (hpp:588); [255] == 1.0f, extra [256] == 0.0f (see floor product)
+  // short blocks (blocksize0 == 256: 64 complex points, one per lane; used by the mixed-block kernel only)
+  float2 pre_s[64];       // pre-rotation of point k = lane
+  float2 post_s[64];      // post-rotation of bin m = bitrev6(lane)
+  float2 tws[6][64];      // DIF stage twiddles: stage i pairs lane l with l ^ (32 >> i); W_(64>>i)^(l & ((32>>i)-1))
+  float wsl[2][64];       // short window at sample s(lane) and at 127 - s(lane)
 };
 
 struct FusedTables {
@@ -57,13 +62,14 @@ struct FusedArgs {
   const vsyn_segment* segs;
   const PktInfo* info;
   const SegInfo* sinfo;
+  const uint8_t* run_cls;  // [S][runs_per_seg] from the layout kernel: 1 long-run kernel, 2 mixed kernel, 0 staged, 0xFF none
   const float* residue;
   const uint16_t* fy;
   float* pcm;
   float* carry;
   DevStatus* status;
   uint64_t plane_stride;
-  uint32_t S, R, fused_ok, coupling_mode;
+  uint32_t S, R, fused_ok, coupling_mode, runs_per_seg;  // fused_ok: bit 0 long-run kernel, bit 1 mixed-block kernel
 };
 
 __device__ __forceinline__ float2 f2(float x, float y) { return make_float2(x, y); }
@@ -365,18 +371,10 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 
 // grid: x = groups of FUSED_WAVES (run, channel) units — the channels of a run sit in adjacent waves of one workgroup so
 // that the partner-channel loads of a coupled pair hit L1/L2 instead of HBM —, y = segment
-static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a workgroup");
 __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_long_kernel(const FusedArgs A) {
   __shared__ FusedLdsImage s_t;
   __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
   __shared__ float4 s_seg[FUSED_WAVES][64];
-  {
-    const uint4* src = (const uint4*)A.lds_image;
-    uint4* dst = (uint4*)&s_t;
-    for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
-  }
-  __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
-
   const ConstHeader* H = hdr_of(A.cb);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
@@ -389,8 +387,14 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   const uint32_t qa = run * A.R;
   const uint32_t qb = min(sg.num_packets, qa + A.R);
   const SegInfo si = A.sinfo[g];
-  const bool active = qa < sg.num_packets &&
-                      run_is_fast(H, A.packets + sg.first_packet, qa, qb, si.has_carry ? si.carry_n : 0u, A.fused_ok);  // else: staged list
+  const bool active = run < A.runs_per_seg && A.run_cls[(size_t)g * A.runs_per_seg + run] == 1;
+  if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing in this workgroup for this kernel: leave before staging the tables
+  {
+    const uint4* src = (const uint4*)A.lds_image;
+    uint4* dst = (uint4*)&s_t;
+    for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
+  }
+  __syncthreads();  // from here on waves only meet at the pair-sharing barriers inside the run loop
   if (!active) {  // keep the workgroup's barrier count balanced
     for (uint32_t it = 0; it <= A.R; ++it) {
       lds_barrier();
@@ -398,12 +402,262 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
     }
     return;
   }
-
-  // coupling structure is fixed per stream setup for the long-block mappings (fused_coupling_mode): channel roles
   const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
   if (A.coupling_mode == 0 || C < 2) fused_run<0>(A, s_t, s_x[wave], s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, c);
   else if (c == mag) fused_run<1>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, ang);
   else fused_run<2>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, mag);
+}
+
+// ================================================================================================
+// Mixed-block runs (short and long blocks, window switches, carry-in from an earlier submit).
+// Same decomposition — one wavefront per (run, channel), channel pairs sharing their input through LDS — but the
+// overlap-add goes through the output buffer itself instead of registers, because consecutive blocks of different size
+// live in different lane layouts: block q stores its windowed right half into the chunk of block q+1 (or into the
+// stream's carry buffer after the last block), and block q+1, in the same wave, adds its windowed left half on top
+// (`buf = 0; buf += prev*w; buf += cur*w`, hpp:1008-1017, with the same two roundings). Short blocks (n = 256) are one
+// complex point per lane: FFT-64 as six cross-lane radix-2 stages.
+// ================================================================================================
+__device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
+
+// floor-1 segment table of one (packet, channel) into seg[] — same construction as in fused_run
+__device__ __forceinline__ bool build_segment_table(const FusedArgs& A, float4* __restrict__ seg, uint32_t lane, const PktInfo& pi,
+                                                    const MapConst* mc, uint32_t c, uint32_t p, uint32_t C, uint32_t ys_stride,
+                                                    uint32_t& sidx_out, uint32_t& floor_id) {
+  if (!((pi.own >> c) & 1u)) {
+    float4 e;
+    e.x = 0.f;
+    e.y = 0.f;
+    e.z = 0.f;
+    e.w = ((pi.used >> c) & 1u) ? 256.f : 255.f;
+    seg[lane] = e;
+    floor_id = 0xFFFFFFFFu;
+    sidx_out = 0;
+    return false;
+  }
+  const uint32_t f = mc->chfloor[c];
+  const FloorConst* fc = floor_of(A.cb, f);
+  const bool in = lane < fc->posts;
+  const uint32_t sidx = in ? fc->sorted_idx[lane] : 0u, xsl = in ? fc->xs_sorted[lane] : 0u;
+  uint32_t v = (A.fy + ((size_t)p * C + c) * ys_stride)[sidx];
+  if (!in) v = 0;
+  const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
+  const uint64_t below = mask & ((2ull << lane) - 1ull);
+  const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
+  const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
+  const bool has_hi = above != 0ull;
+  const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
+  const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
+  const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
+  const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
+  const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
+  const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
+  const float inv = has_hi ? 1.0f / (x1 - x0) : 0.f;
+  const float ady = fabsf(y1 - y0);
+  float4 e;
+  e.x = ady * inv;
+  e.y = __builtin_fmaf(-ady, x0, 0.5f) * inv;
+  e.z = y1 >= y0 ? 1.f : -1.f;
+  e.w = y0;
+  seg[lane] = e;
+  floor_id = f;
+  sidx_out = sidx;
+  return (v & 0x7FFFu) > 255u;  // hpp:587
+}
+
+__device__ __forceinline__ float floor_at(const float4* __restrict__ seg, const FusedLdsImage& T, const uint8_t* __restrict__ binseg_row, uint32_t x) {
+  const float4 sgm = seg[binseg_row[x]];
+  const float qf = floorf(__builtin_fmaf((float)x, sgm.x, sgm.y));
+  return T.invdb[(uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w)];
+}
+
+template <int ROLE>
+__device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb,
+                                                float4* __restrict__ seg, const uint32_t lane, const uint32_t g, const vsyn_segment sg,
+                                                const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c,
+                                                const uint32_t pc) {
+  const uint8_t* __restrict__ cb = A.cb;
+  const ConstHeader* H = hdr_of(cb);
+  const uint32_t num = sg.num_packets, half1 = H->bs[1] / 2;
+  const uint32_t kappa = ((lane & 7u) << 3) | (lane >> 3), mirror = 63u - lane;
+  float* const plane = A.pcm + ((size_t)g * C + c) * A.plane_stride;
+  const size_t carry_half = (size_t)H->max_streams * C * half1;
+  float* const carry_out = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * half1;
+  const uint32_t q0 = qa ? qa - 1 : 0;
+
+  if (qa == 0 && si.has_carry) {
+    // the previous submit left this stream's windowed right half in natural order: it is the "prev" term of chunk 0
+    const PktInfo p0 = A.info[sg.first_packet];
+    const float* cin = A.carry + si.parity_in * carry_half + ((size_t)sg.stream * C + c) * half1;
+    const uint32_t cnt = min(p0.emit, si.carry_n / 2u);
+    for (uint32_t i = lane; i < cnt; i += 64) plane[p0.out_pos + i] = cin[i];
+  }
+  uint32_t prev_half = (qa == 0) ? (si.has_carry ? si.carry_n / 2u : 0u) : 0u;  // samples the previous block put into this chunk
+
+  for (uint32_t it = 0; it <= A.R; ++it) {
+    const uint32_t q = q0 + it;
+    if (q >= qb) {
+      lds_barrier();
+      lds_barrier();
+      continue;
+    }
+    const uint32_t p = sg.first_packet + q;
+    const PktInfo pi = A.info[p];
+    const bool halo = q < qa, last_of_segment = q + 1 == num;
+    const PktInfo pin = A.info[last_of_segment ? p : p + 1];
+    const MapConst* mc = map_of(cb, pi.mapping);
+    const bool lng = pi.lng != 0;
+    const uint32_t M = pi.n / 2u;
+    // make the previous block's right-half stores (any lane) visible to this block's loads of the same chunk
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ---- residue + coupling (pair shares its input through LDS, as in fused_run) -------------------------------
+    float2 r[8];
+    {
+      const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t == 0 || lng) r[t] = src[lane + 64 * t];
+    }
+    if (ROLE != 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t == 0 || lng) xb[t * 64 + lane] = r[t];
+    }
+    lds_barrier();
+    if (ROLE != 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t == 0 || lng) {
+          const float2 oth = pxb[t * 64 + lane];
+          r[t] = ROLE == 1 ? f2(couple_mag(r[t].x, oth.x), couple_mag(r[t].y, oth.y)) : f2(couple_ang(oth.x, r[t].x), couple_ang(oth.y, r[t].y));
+        }
+    }
+    lds_barrier();
+
+    // ---- floor curve + product ---------------------------------------------------------------------------------
+    uint32_t sidx_unused, floor_id;
+    const bool floor_bad = build_segment_table(A, seg, lane, pi, mc, c, p, C, H->ys_stride, sidx_unused, floor_id);
+    {
+      // bin -> sorted-post interval: row of this floor (any row works for the constant entry of a curve-less channel)
+      const uint8_t* brow = A.binseg + (size_t)(floor_id == 0xFFFFFFFFu ? 0u : floor_id) * half1;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t == 0 || lng) {
+          const uint32_t x = 2u * (lane + 64u * t);
+          const uint32_t b0 = floor_id == 0xFFFFFFFFu ? 0u : x, b1 = floor_id == 0xFFFFFFFFu ? 0u : x + 1u;
+          const float4 s0 = seg[floor_id == 0xFFFFFFFFu ? lane : brow[b0]], s1 = seg[floor_id == 0xFFFFFFFFu ? lane : brow[b1]];
+          const float q0f = floorf(__builtin_fmaf((float)x, s0.x, s0.y)), q1f = floorf(__builtin_fmaf((float)(x + 1u), s1.x, s1.y));
+          r[t] = f2(r[t].x * T.invdb[(uint32_t)__builtin_fmaf(q0f, s0.z, s0.w)], r[t].y * T.invdb[(uint32_t)__builtin_fmaf(q1f, s1.z, s1.w)]);
+        }
+    }
+    if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
+
+    // ---- where the two halves of this block go ------------------------------------------------------------------
+    // chunk q = [centre(q-1), centre(q)): left-half sample j of this block sits at j + L - M, L = prev/4 + n/4 frames
+    const uint32_t emit = halo ? 0u : pi.emit;
+    float* const outq = plane + pi.out_pos;
+    // natural frames of the chunk: what the layout kernel derived emit from (emit may be clipped by the page granule)
+    const uint32_t Lq = prev_half ? prev_half / 2u + M / 2u : 0u;
+    const int32_t left_shift = (int32_t)Lq - (int32_t)M;
+    // right half: into the next chunk (only if this wave also owns it, or this is the halo), or into the carry buffer
+    const bool store_right = last_of_segment || (q + 1 < qb);
+    float* const nxt = last_of_segment ? carry_out : plane + pin.out_pos;
+    const uint32_t nlimit = last_of_segment ? M : ((q + 1 >= qa) ? pin.emit : 0u);
+
+    if (lng) {
+      // ---- IMDCT (as in fused_run) ----
+      float2 z[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float im = __shfl(r[7 - t].y, (int)mirror);
+        z[t] = cmulf(f2(r[t].x, im), T.pre[t][lane]);
+      }
+      fft512_wave(z, xb, &T, lane);
+      const float (*TL)[8][64] = T.win[pi.widx & 1u];
+      const float (*TN)[8][64] = T.win[(pi.widx >> 1) & 1u];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float2 d = cmulf(z[k], T.post[k][lane]);
+        const uint32_t m = kappa + 64u * k;
+        const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m, sm = 1023u - s;
+        const float cc = k >= 4 ? d.x : -d.y, pn = k >= 4 ? d.y : -d.x;
+        const float vl_s = cc * TL[0][k][lane], vl_m = (-cc) * TL[1][k][lane];
+        const int32_t ps = (int32_t)s + left_shift, pm = (int32_t)sm + left_shift;
+        if (ps >= 0 && (uint32_t)ps < emit) outq[ps] = ((uint32_t)ps < prev_half ? outq[ps] : 0.f) + vl_s;
+        if (pm >= 0 && (uint32_t)pm < emit) outq[pm] = ((uint32_t)pm < prev_half ? outq[pm] : 0.f) + vl_m;
+        if (store_right) {
+          if (s < nlimit) nxt[s] = pn * TN[1][k][lane];
+          if (sm < nlimit) nxt[sm] = pn * TN[0][k][lane];
+        }
+      }
+    } else {
+      // ---- short block: one point per lane ----
+      const float im = __shfl(r[0].y, (int)mirror);  // X[127 - 2k] lives in lane 63-k
+      float2 z = cmulf(f2(r[0].x, im), T.pre_s[lane]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {  // radix-2 decimation in frequency across lanes: partner l ^ d, d = 32 .. 1
+        const int d = 32 >> i;
+        const float ox = __shfl_xor(z.x, d), oy = __shfl_xor(z.y, d);
+        const bool upper = (lane & (uint32_t)d) != 0;
+        const float2 sum = f2(z.x + ox, z.y + oy);
+        const float2 dif = cmulf(f2(ox - z.x, oy - z.y), T.tws[i][lane]);  // (lower - upper) * W, evaluated in the upper lane
+        z = upper ? dif : sum;
+      }
+      const float2 d = cmulf(z, T.post_s[lane]);
+      const uint32_t m = bitrev6(lane);
+      const bool hi = m >= 32u;
+      const uint32_t s = hi ? 2u * m - 64u : 63u - 2u * m, sm = 127u - s;
+      const float cc = hi ? d.x : -d.y, pn = hi ? d.y : -d.x;
+      const float vl_s = cc * T.wsl[0][lane], vl_m = (-cc) * T.wsl[1][lane];
+      const int32_t ps = (int32_t)s + left_shift, pm = (int32_t)sm + left_shift;
+      if (ps >= 0 && (uint32_t)ps < emit) outq[ps] = ((uint32_t)ps < prev_half ? outq[ps] : 0.f) + vl_s;
+      if (pm >= 0 && (uint32_t)pm < emit) outq[pm] = ((uint32_t)pm < prev_half ? outq[pm] : 0.f) + vl_m;
+      if (store_right) {
+        if (s < nlimit) nxt[s] = pn * T.wsl[1][lane];
+        if (sm < nlimit) nxt[sm] = pn * T.wsl[0][lane];
+      }
+    }
+    prev_half = M;
+  }
+}
+
+static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a workgroup");
+__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_mixed_kernel(const FusedArgs A) {
+  __shared__ FusedLdsImage s_t;
+  __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
+  __shared__ float4 s_seg[FUSED_WAVES][64];
+  const ConstHeader* H = hdr_of(A.cb);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = blockIdx.y, C = H->channels;
+  if (g >= A.S) return;
+  const vsyn_segment sg = A.segs[g];
+  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // whole workgroup: the layout kernel flagged the segment
+  const uint32_t unit = blockIdx.x * FUSED_WAVES + wave;
+  const uint32_t run = unit / C, c = unit % C;
+  const uint32_t qa = run * A.R;
+  const uint32_t qb = min(sg.num_packets, qa + A.R);
+  const SegInfo si = A.sinfo[g];
+  const bool active = run < A.runs_per_seg && A.run_cls[(size_t)g * A.runs_per_seg + run] == 2;
+  if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing in this workgroup for this kernel: leave before staging the tables
+  {
+    const uint4* src = (const uint4*)A.lds_image;
+    uint4* dst = (uint4*)&s_t;
+    for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
+  }
+  __syncthreads();  // from here on waves only meet at the pair-sharing barriers inside the run loop
+  if (!active) {  // keep the workgroup's barrier count balanced
+    for (uint32_t it = 0; it <= A.R; ++it) {
+      lds_barrier();
+      lds_barrier();
+    }
+    return;
+  }
+  const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
+  if (A.coupling_mode == 0 || C < 2) fused_mixed_run<0>(A, s_t, s_x[wave], s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, c);
+  else if (c == mag) fused_mixed_run<1>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, ang);
+  else fused_mixed_run<2>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, mag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,12 +683,33 @@ static inline int fused_coupling_mode(const ConstHeader& H, const uint8_t* host_
   return mode == -2 ? 0 : mode;
 }
 
+// bit 0: long-run kernel usable, bit 1: mixed-block kernel usable (needs blocksize0 == 256 and the same coupling
+// structure in every mapping, short-block modes included)
+static inline uint32_t fused_ok_mask(const ConstHeader& H, const uint8_t* host_const);
+
 static inline bool fused_setup_ok(const ConstHeader& H, const uint8_t* host_const) {
   if (!fused_supported(H)) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
   for (uint32_t f = 0; f < H.num_floors; ++f)
     if (fl[f].posts > 64) return false;  // one ballot covers the sorted posts
   return fused_coupling_mode(H, host_const) >= 0;
+}
+
+static inline uint32_t fused_ok_mask(const ConstHeader& H, const uint8_t* host_const) {
+  if (!fused_setup_ok(H, host_const)) return 0;
+  uint32_t mask = 1;
+  if (H.bs[0] == 256) {
+    const MapConst* mp = (const MapConst*)(host_const + H.off_map);
+    const int want = fused_coupling_mode(H, host_const);
+    bool same = true;
+    for (uint32_t k = 0; k < H.num_modes; ++k) {
+      const MapConst& m = mp[H.mode_mapping[k]];
+      const int cur = m.ncoup == 0 ? 0 : (m.ncoup == 1 ? (m.coup[0] == 0 ? 1 : 2) : -1);
+      same = same && cur == want;
+    }
+    if (same) mask |= 2;
+  }
+  return mask;
 }
 
 static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t* host_const, FusedTables* ft) {
@@ -477,6 +752,25 @@ static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t
     for (uint32_t a = 0; a < 8; ++a)
       for (uint32_t c = 0; c < 8; ++c) im.tw2[a][c] = tw[(8 * c * a) & 511u];
     memcpy(im.invdb, host_const + H.off_invdb, 256 * sizeof(float));
+    if (H.bs[0] == 256) {
+      const float2* pre0 = (const float2*)(host_const + H.off_pre[0]);
+      const float2* post0 = (const float2*)(host_const + H.off_post[0]);
+      const float2* tw0 = (const float2*)(host_const + H.off_fft[0]);  // W64^j
+      const float* win0 = (const float*)(host_const + H.off_win[0]);
+      for (uint32_t l = 0; l < 64; ++l) {
+        uint32_t m = 0;
+        for (int b = 0; b < 6; ++b) m |= ((l >> b) & 1u) << (5 - b);
+        im.pre_s[l] = pre0[l];
+        im.post_s[l] = post0[m];
+        for (int i = 0; i < 6; ++i) {
+          const uint32_t d = 32u >> i;
+          im.tws[i][l] = tw0[((l & (d - 1u)) * (32u / d)) & 63u];
+        }
+        const uint32_t sidx = m >= 32 ? 2 * m - 64 : 63 - 2 * m;
+        im.wsl[0][l] = win0[sidx];
+        im.wsl[1][l] = win0[127 - sidx];
+      }
+    }
     e = hipMalloc((void**)&ft->d_lds, sizeof(FusedLdsImage));
     if (e != hipSuccess) return e;
     e = hipMemcpy(ft->d_lds, &im, sizeof(FusedLdsImage), hipMemcpyHostToDevice);
@@ -516,6 +810,15 @@ static inline hipError_t fused_launch(const ConstHeader& H, const FusedTables& f
   const size_t dyn = xl ? (size_t)atoi(xl) : 0;
   a.coupling_mode = (uint32_t)ft.coupling_mode;
   vsyn_fused_long_kernel<<<grid, FUSED_WAVES * 64, dyn, s>>>(a);
+  return hipGetLastError();
+}
+
+// runs with short blocks / window switches / a carry-in: same grid, every wave of a run the long kernel took idles out
+static inline hipError_t fused_mixed_launch(const ConstHeader& H, const FusedTables& ft, FusedArgs a, uint32_t max_seg_packets, hipStream_t s) {
+  const uint32_t units = ((max_seg_packets + a.R - 1) / a.R) * H.channels;
+  dim3 grid((units + FUSED_WAVES - 1) / FUSED_WAVES, a.S);
+  a.coupling_mode = (uint32_t)ft.coupling_mode;
+  vsyn_fused_mixed_kernel<<<grid, FUSED_WAVES * 64, 0, s>>>(a);
   return hipGetLastError();
 }
 

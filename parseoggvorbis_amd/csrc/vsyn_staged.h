@@ -29,15 +29,23 @@ __device__ __forceinline__ AbsScan abs_combine(AbsScan a, AbsScan b) {
 
 // Shared by the layout kernel (which builds the staged list) and the fused kernel (which skips non-fast runs):
 // both must take the same decision.
-__device__ __forceinline__ bool run_is_fast(const ConstHeader* H, const vsyn_packet* __restrict__ spk, uint32_t qa, uint32_t qb,
-                                            uint32_t carry_n, uint32_t fused_ok) {
-  if (!fused_ok) return false;
-  if (qa == 0 && carry_n) return false;  // a carry-in from an earlier submit is in natural order: staged kernels take that run
+// Which kernel takes a run of packets [qa, qb) of a segment: 1 = fused long-run kernel (every packet it touches, its
+// one-packet halo included, is a long block and there is no carry-in from an earlier submit), 2 = fused mixed-block
+// kernel (any mix of valid short/long blocks, carry-in allowed), 0 = staged work list. Shared by the layout kernel
+// (which builds the list) and the fused kernels (which skip what is not theirs): all three must agree.
+__device__ __forceinline__ uint32_t run_class(const ConstHeader* H, const vsyn_packet* __restrict__ spk, uint32_t qa, uint32_t qb,
+                                              uint32_t carry_n, uint32_t ok_mask) {
+  if (!ok_mask) return 0;
+  bool all_long = !(qa == 0 && carry_n), all_valid = true;
   for (uint32_t q = qa ? qa - 1 : 0; q < qb; ++q) {
     const uint32_t m = spk[q].mode;
-    if (!(m < H->num_modes && H->mode_blockflag[m])) return false;
+    const bool valid = m < H->num_modes;
+    all_valid = all_valid && valid;
+    all_long = all_long && valid && H->mode_blockflag[m];
   }
-  return true;
+  if (all_long && (ok_mask & 1u)) return 1;
+  if (all_valid && (ok_mask & 2u)) return 2;
+  return 0;
 }
 
 __global__ void __launch_bounds__(256)
@@ -45,7 +53,8 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
                    const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
                    SegInfo* __restrict__ sinfo, StreamState* __restrict__ state, uint32_t* __restrict__ emit_len,
                    DevStatus* __restrict__ status, uint32_t R, uint32_t fused_ok, uint32_t* __restrict__ staged_list,
-                   uint32_t* __restrict__ staged_count, uint32_t* __restrict__ next_count, uint32_t* __restrict__ seg_of_pkt) {
+                   uint32_t* __restrict__ staged_count, uint32_t* __restrict__ next_count, uint32_t* __restrict__ seg_of_pkt,
+                   uint8_t* __restrict__ run_cls, uint32_t runs_per_seg) {
   const ConstHeader* H = hdr_of(cb);
   const uint32_t g = blockIdx.x, t = threadIdx.x;
   if (g >= S) return;
@@ -57,6 +66,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       raise_status(status, VSYN_ST_BAD_SEGMENT, sg.first_packet < P ? sg.first_packet : 0);
       sinfo[g] = SegInfo{0, 0, 0, 0};
     }
+    for (uint32_t r = t; r < runs_per_seg; r += 256) run_cls[(size_t)g * runs_per_seg + r] = 0xFFu;
     // mark every packet we may safely touch as bad so later kernels skip it
     if ((uint64_t)sg.first_packet + sg.num_packets <= P)
       for (uint32_t q = t; q < sg.num_packets; q += 256) {
@@ -219,10 +229,12 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   // appended to the staged work list (entry = packet index | emit << 31; halo packets carry emit = 0).
   {
     const uint32_t nruns = (num + R - 1) / R;
-    for (uint32_t r = t; r < nruns; r += 256) {
+    for (uint32_t r = t; r < runs_per_seg; r += 256) {
       const uint32_t qa = r * R, qb2 = min(num, qa + R);
-      if (run_is_fast(H, spk, qa, qb2, carry_n, fused_ok)) continue;
-      const bool prev_fast = qa > 0 && run_is_fast(H, spk, qa - R, qa, carry_n, fused_ok);
+      const uint32_t cls = r < nruns ? run_class(H, spk, qa, qb2, carry_n, fused_ok) : 0xFFu;  // 0xFF: no such run
+      run_cls[(size_t)g * runs_per_seg + r] = (uint8_t)cls;  // the fused kernels read this instead of re-deriving it
+      if (r >= nruns || cls) continue;
+      const bool prev_fast = qa > 0 && run_class(H, spk, qa - R, qa, carry_n, fused_ok) != 0;
       const uint32_t cnt = (qb2 - qa) + (prev_fast ? 1u : 0u);
       uint32_t at = atomicAdd(staged_count, cnt);
       if (prev_fast) staged_list[at++] = sg.first_packet + qa - 1;  // IMDCT only: the overlap of `qa` reads its block
