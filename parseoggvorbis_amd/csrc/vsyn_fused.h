@@ -235,7 +235,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       e.x = 0.f;
       e.y = 0.f;
       e.z = 0.f;
-      e.w = ((pi.used >> c) & 1u) ? 256.f : 255.f;
+      e.w = ((pi.used >> c) & 1u) ? 4.f * 256.f : 4.f * 255.f;
       seg[lane] = e;
     } else {
       const uint32_t f = mc->chfloor[c];
@@ -273,13 +273,14 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       floor_bad = (v & 0x7FFFu) > 255u;  // a post above 255 can only render >= 256 (hpp:587)
       const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
       const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
-      const float inv = has_hi ? 1.0f / (x1 - x0) : 0.f;
+      // 1/adx: v_rcp_f32 (1 ulp) is enough — the guard band above leaves 8x headroom over the total rounding
+      const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
       const float ady = fabsf(y1 - y0);
       float4 e;
       e.x = ady * inv;
       e.y = __builtin_fmaf(-ady, x0, 0.5f) * inv;
-      e.z = y1 >= y0 ? 1.f : -1.f;
-      e.w = y0;
+      e.z = y1 >= y0 ? 4.f : -4.f;  // table index pre-scaled to a byte offset into invdb[]
+      e.w = 4.f * y0;
       seg[lane] = e;
     }
     // coded posts of packet q+1, one packet ahead (valid if the floor does not change)
@@ -298,7 +299,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         const uint32_t sidx_b = (bseg[b >> 2] >> (8 * (b & 3))) & 0xFFu;
         const float4 sgm = seg[sidx_b];
         const float qf = floorf(__builtin_fmaf(xf0 + (float)(128 * t + e), sgm.x, sgm.y));
-        fl2[e] = T.invdb[(uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w)];  // index 0..255 between two posts <= 255
+        const uint32_t byte_off = (uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w);  // 4 * index, index 0..255 between two posts <= 255
+        fl2[e] = *(const float*)((const char*)T.invdb + byte_off);
       }
       r[t] = f2(r[t].x * fl2[0], r[t].y * fl2[1]);
     }
