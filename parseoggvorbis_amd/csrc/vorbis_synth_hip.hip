@@ -518,7 +518,11 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   hipStream_t ss = force_staged ? s : h->side;
   if (!force_staged) HIPCHK(hipStreamWaitEvent(h->side, h->ev_pre_done[wb], 0));
   {
-    const size_t bound = (size_t)P * C * (H.bs[1] / 2);  // residue floats upper bound (device-resident descriptors)
+    // residue floats upper bound (the descriptors are device resident, so the exact sum is not known here). With the
+    // mixed-block kernel available the staged list can only hold packets with an invalid mode, which the staged kernels
+    // skip before touching these buffers: a token allocation is enough then.
+    const bool staged_may_work = force_staged || !(h->fused_mask & 2u);
+    const size_t bound = staged_may_work ? (size_t)P * C * (H.bs[1] / 2) : 64;
     float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
     float* blk = taps && taps->pcm_after_mdct ? taps->pcm_after_mdct : nullptr;
     if (!env) {

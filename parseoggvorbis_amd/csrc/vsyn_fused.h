@@ -420,6 +420,7 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
 // complex point per lane: FFT-64 as six cross-lane radix-2 stages.
 // ================================================================================================
 __device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
+__device__ __forceinline__ bool spk_mode_invalid(const ConstHeader* H, uint32_t mode) { return mode >= H->num_modes; }
 
 // floor-1 segment table of one (packet, channel) into seg[] — same construction as in fused_run
 __device__ __forceinline__ bool build_segment_table(const FusedArgs& A, float4* __restrict__ seg, uint32_t lane, const PktInfo& pi,
@@ -506,6 +507,13 @@ __device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedL
     const PktInfo pi = A.info[p];
     const bool halo = q < qa, last_of_segment = q + 1 == num;
     const PktInfo pin = A.info[last_of_segment ? p : p + 1];
+    if (spk_mode_invalid(H, A.packets[p].mode)) {
+      // invalid mode number: the layout kernel flagged it; nothing to synthesise (outputs after it are unspecified)
+      lds_barrier();
+      lds_barrier();
+      prev_half = 0;
+      continue;
+    }
     const MapConst* mc = map_of(cb, pi.mapping);
     const bool lng = pi.lng != 0;
     const uint32_t M = pi.n / 2u;

@@ -44,7 +44,8 @@ __device__ __forceinline__ uint32_t run_class(const ConstHeader* H, const vsyn_p
     all_long = all_long && valid && H->mode_blockflag[m];
   }
   if (all_long && (ok_mask & 1u)) return 1;
-  if (all_valid && (ok_mask & 2u)) return 2;
+  if (ok_mask & 2u) return 2;  // the mixed kernel also steps over packets with an invalid mode (PktInfo.bad)
+  (void)all_valid;
   return 0;
 }
 
