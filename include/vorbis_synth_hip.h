@@ -159,7 +159,8 @@ int vsyn_submit_device(vsyn_handle* h,
                        uint32_t* d_emit_len, const vsyn_taps* d_taps,
                        uint32_t flags, void* hip_stream, const char** err);
 
-/* Same with HOST pointers: stages to the device, runs, copies pcm / emit_len / taps back, synchronises,
+/* Same with HOST pointers: stages to the device, runs, copies pcm / emit_len / taps back, synchronises (on a stream owned
+ * by the handle: calls on different handles from different host threads overlap),
  * and returns VSYN_ERR_STREAM (status filled) if the device flagged the batch. residue_floats = total floats in residue. */
 int vsyn_submit_host(vsyn_handle* h,
                      uint32_t num_packets, const vsyn_packet* packets,
@@ -168,6 +169,11 @@ int vsyn_submit_host(vsyn_handle* h,
                      float* pcm, uint64_t plane_stride,
                      uint32_t* emit_len, const vsyn_taps* taps,
                      uint32_t flags, vsyn_status* status, const char** err);
+
+/* Page-locked host memory for the buffers handed to vsyn_submit_host (direct DMA instead of the runtime's staging copies;
+ * what a host decoder that batches at corpus scale wants). Pageable memory is accepted by vsyn_submit_host as well. */
+int vsyn_host_alloc(size_t bytes, void** out, const char** err);
+void vsyn_host_free(void* p);
 
 /* Waits for hip_stream and returns the accumulated device status since the last call (then clears it). */
 int vsyn_sync_status(vsyn_handle* h, void* hip_stream, vsyn_status* status, const char** err);

@@ -105,7 +105,7 @@ class SetupSpec:
 _SYMBOLS = [
     "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels",
     "vsyn_const_block_bytes", "vsyn_submit_device", "vsyn_submit_host", "vsyn_sync_status", "vsyn_reset_streams",
-    "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device",
+    "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device", "vsyn_host_alloc", "vsyn_host_free",
 ]
 
 

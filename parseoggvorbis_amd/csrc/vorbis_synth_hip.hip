@@ -96,6 +96,7 @@ struct vsyn_handle {
   bool fused_ok = false;
   uint32_t fused_mask = 0;
   int num_cus = 256;
+  hipStream_t host_stream = nullptr;   // vsyn_submit_host: copies in, kernels, copies out
   hipStream_t side = nullptr;          // the (usually empty) staged work list runs beside the fused kernel
   hipStream_t pre = nullptr;           // layout + floor unwrap of submit i+1 run beside the fused kernel of submit i
   hipEvent_t ev_join = nullptr, ev_pre_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr};
@@ -336,6 +337,7 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HC(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   HC(hipStreamCreateWithFlags(&h->pre, hipStreamNonBlocking));
+  HC(hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking));
   HC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   for (int b = 0; b < 2; ++b) {
     HC(hipEventCreateWithFlags(&h->ev_pre_done[b], hipEventDisableTiming));
@@ -361,6 +363,7 @@ void vsyn_destroy(vsyn_handle* h) {
   fused_tables_destroy(&h->fused);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->pre) (void)hipStreamDestroy(h->pre);
+  if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (int b = 0; b < 2; ++b) {
     if (h->ev_pre_done[b]) (void)hipEventDestroy(h->ev_pre_done[b]);
@@ -629,29 +632,45 @@ int vsyn_submit_host(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uin
   if (taps && taps->floor_final) {
     HIPCHK(h->st_fy.ensure(ys_n));
     dt.floor_final = h->st_fy.p;
-    HIPCHK(hipMemset(h->st_fy.p, 0, ys_n * sizeof(uint16_t)));
   }
-  HIPCHK(hipMemcpy(h->st_pk.p, packets, sizeof(vsyn_packet) * P, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->st_seg.p, segments, sizeof(vsyn_segment) * S, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->st_ys.p, ys, sizeof(uint16_t) * ys_n, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->st_res.p, residue, sizeof(float) * residue_floats, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(h->st_pcm.p, 0, sizeof(float) * pcm_n));
-  if (dt.after_envelope) HIPCHK(hipMemset(dt.after_envelope, 0, sizeof(float) * residue_floats));
-  if (dt.pcm_after_mdct) HIPCHK(hipMemset(dt.pcm_after_mdct, 0, sizeof(float) * 2 * residue_floats));
+  // Everything runs on the handle's own stream, so that several handles driven from several host threads overlap their
+  // copies and kernels (the NULL stream would serialise them). With pinned host buffers (vsyn_host_alloc) the copies are
+  // direct DMA; pageable buffers work too, staged by the runtime.
+  hipStream_t hs = h->host_stream;
+  HIPCHK(hipMemcpyAsync(h->st_pk.p, packets, sizeof(vsyn_packet) * P, hipMemcpyHostToDevice, hs));
+  HIPCHK(hipMemcpyAsync(h->st_seg.p, segments, sizeof(vsyn_segment) * S, hipMemcpyHostToDevice, hs));
+  HIPCHK(hipMemcpyAsync(h->st_ys.p, ys, sizeof(uint16_t) * ys_n, hipMemcpyHostToDevice, hs));
+  HIPCHK(hipMemcpyAsync(h->st_res.p, residue, sizeof(float) * residue_floats, hipMemcpyHostToDevice, hs));
+  HIPCHK(hipMemsetAsync(h->st_pcm.p, 0, sizeof(float) * pcm_n, hs));
+  if (dt.floor_final) HIPCHK(hipMemsetAsync(h->st_fy.p, 0, ys_n * sizeof(uint16_t), hs));
+  if (dt.after_envelope) HIPCHK(hipMemsetAsync(dt.after_envelope, 0, sizeof(float) * residue_floats, hs));
+  if (dt.pcm_after_mdct) HIPCHK(hipMemsetAsync(dt.pcm_after_mdct, 0, sizeof(float) * 2 * residue_floats, hs));
   const bool any_tap = dt.after_envelope || dt.pcm_after_mdct || dt.floor_final;
   int rc = vsyn_submit_device(h, P, h->st_pk.p, S, h->st_seg.p, max_seg, h->st_ys.p, h->st_res.p, h->st_pcm.p, plane_stride,
-                              h->st_emit.p, any_tap ? &dt : nullptr, flags, nullptr, err);
+                              h->st_emit.p, any_tap ? &dt : nullptr, flags, hs, err);
   if (rc) return rc;
+  // results are queued behind the kernels before the one host wait
+  HIPCHK(hipMemcpyAsync(pcm, h->st_pcm.p, sizeof(float) * pcm_n, hipMemcpyDeviceToHost, hs));
+  if (emit_len) HIPCHK(hipMemcpyAsync(emit_len, h->st_emit.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, hs));
+  if (dt.after_envelope) HIPCHK(hipMemcpyAsync(taps->after_envelope, dt.after_envelope, sizeof(float) * residue_floats, hipMemcpyDeviceToHost, hs));
+  if (dt.pcm_after_mdct) HIPCHK(hipMemcpyAsync(taps->pcm_after_mdct, dt.pcm_after_mdct, sizeof(float) * 2 * residue_floats, hipMemcpyDeviceToHost, hs));
+  if (dt.floor_final) HIPCHK(hipMemcpyAsync(taps->floor_final, dt.floor_final, sizeof(uint16_t) * ys_n, hipMemcpyDeviceToHost, hs));
   vsyn_status st;
-  rc = vsyn_sync_status(h, nullptr, &st, err);
+  rc = vsyn_sync_status(h, hs, &st, err);
   if (status) *status = st;
-  if (rc != VSYN_OK && rc != VSYN_ERR_STREAM) return rc;
-  HIPCHK(hipMemcpy(pcm, h->st_pcm.p, sizeof(float) * pcm_n, hipMemcpyDeviceToHost));
-  if (emit_len) HIPCHK(hipMemcpy(emit_len, h->st_emit.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost));
-  if (dt.after_envelope) HIPCHK(hipMemcpy(taps->after_envelope, dt.after_envelope, sizeof(float) * residue_floats, hipMemcpyDeviceToHost));
-  if (dt.pcm_after_mdct) HIPCHK(hipMemcpy(taps->pcm_after_mdct, dt.pcm_after_mdct, sizeof(float) * 2 * residue_floats, hipMemcpyDeviceToHost));
-  if (dt.floor_final) HIPCHK(hipMemcpy(taps->floor_final, dt.floor_final, sizeof(uint16_t) * ys_n, hipMemcpyDeviceToHost));
   return rc;
+}
+
+int vsyn_host_alloc(size_t bytes, void** out, const char** err) {
+  if (!out) return fail(err, VSYN_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return VSYN_OK;
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return VSYN_OK;
+}
+
+void vsyn_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int vsyn_imdct_device(vsyn_handle* h, uint32_t n, uint32_t count, const float* d_in, float* d_out, void* hip_stream, const char** err) {

@@ -535,51 +535,72 @@ OkOrError VorbisStream::parse_setup(const uint8_t* data, uint32_t len, ParseCall
   return OkOrError();
 }
 
-// The synthesis-relevant part of the setup, handed to the GPU layer once per stream.
-static OkOrError make_synth(VorbisStream& st) {
+// The synthesis-relevant part of the setup, handed to the GPU layer once per stream (or once per group of streams that
+// share it: `key` serialises exactly what vsyn_create reads).
+OkOrError build_synth_setup(const VorbisStream& st, SynthSetup& o) {
   const uint32_t C = st.header.audio_channels;
   CHECK(C >= 1 && C <= VSYN_MAX_CHANNELS);
-  std::vector<vsyn_floor1> floors(st.setup.floors.size());
-  static const uint32_t dummy_xs[2] = {0, 1};
-  for (size_t i = 0; i < floors.size(); ++i) {
+  o.floors.resize(st.setup.floors.size());
+  o.xs.resize(st.setup.floors.size());
+  for (size_t i = 0; i < o.floors.size(); ++i) {
     const VorbisFloor& f = st.setup.floors[i];
     if (f.floor_type == 1) {
-      floors[i].multiplier = f.floor1.multiplier;
-      floors[i].num_posts = (uint32_t)f.floor1.xs.size();
-      floors[i].xs = f.floor1.xs.data();
+      o.xs[i] = f.floor1.xs;
+      o.floors[i].multiplier = f.floor1.multiplier;
     } else {  // type 0 cannot be decoded (packets using it fail earlier); keep the table slot well-formed
-      floors[i].multiplier = 1;
-      floors[i].num_posts = 2;
-      floors[i].xs = dummy_xs;
+      o.xs[i] = {0u, 1u};
+      o.floors[i].multiplier = 1;
     }
+    o.floors[i].num_posts = (uint32_t)o.xs[i].size();
+    o.floors[i].xs = o.xs[i].data();
   }
-  std::vector<std::vector<vsyn_coupling>> coup(st.setup.mappings.size());
-  std::vector<std::vector<uint8_t>> chfloor(st.setup.mappings.size());
-  std::vector<vsyn_mapping> maps(st.setup.mappings.size());
-  for (size_t m = 0; m < maps.size(); ++m) {
+  o.coup.resize(st.setup.mappings.size());
+  o.chfloor.resize(st.setup.mappings.size());
+  o.maps.resize(st.setup.mappings.size());
+  for (size_t m = 0; m < o.maps.size(); ++m) {
     const VorbisMapping& mp = st.setup.mappings[m];
-    for (const VorbisMapping::Coupling& c : mp.couplings) coup[m].push_back(vsyn_coupling{(uint16_t)c.magintude, (uint16_t)c.angle});
-    for (uint32_t c = 0; c < C; ++c) chfloor[m].push_back(mp.submaps[mp.muxs[c]].floor);
-    maps[m].num_couplings = (uint32_t)coup[m].size();
-    maps[m].couplings = coup[m].data();
-    maps[m].channel_floor = chfloor[m].data();
+    for (const VorbisMapping::Coupling& c : mp.couplings) o.coup[m].push_back(vsyn_coupling{(uint16_t)c.magintude, (uint16_t)c.angle});
+    for (uint32_t c = 0; c < C; ++c) o.chfloor[m].push_back(mp.submaps[mp.muxs[c]].floor);
+    o.maps[m].num_couplings = (uint32_t)o.coup[m].size();
+    o.maps[m].couplings = o.coup[m].data();
+    o.maps[m].channel_floor = o.chfloor[m].data();
   }
-  std::vector<vsyn_mode> modes(st.setup.modes.size());
-  for (size_t k = 0; k < modes.size(); ++k) modes[k] = vsyn_mode{(uint8_t)(st.setup.modes[k].block_flag ? 1 : 0), st.setup.modes[k].mapping};
-  vsyn_setup su;
-  su.channels = C;
-  su.blocksize0 = st.header.get_blocksize_0();
-  su.blocksize1 = st.header.get_blocksize_1();
-  su.num_floors = (uint32_t)floors.size();
-  su.floors = floors.data();
-  su.num_mappings = (uint32_t)maps.size();
-  su.mappings = maps.data();
-  su.num_modes = (uint32_t)modes.size();
-  su.modes = modes.data();
+  o.modes.resize(st.setup.modes.size());
+  for (size_t k = 0; k < o.modes.size(); ++k) o.modes[k] = vsyn_mode{(uint8_t)(st.setup.modes[k].block_flag ? 1 : 0), st.setup.modes[k].mapping};
+  o.su.channels = C;
+  o.su.blocksize0 = st.header.get_blocksize_0();
+  o.su.blocksize1 = st.header.get_blocksize_1();
+  o.su.num_floors = (uint32_t)o.floors.size();
+  o.su.floors = o.floors.data();
+  o.su.num_mappings = (uint32_t)o.maps.size();
+  o.su.mappings = o.maps.data();
+  o.su.num_modes = (uint32_t)o.modes.size();
+  o.su.modes = o.modes.data();
+  std::string& k = o.key;
+  auto put = [&k](uint32_t v) { k.append((const char*)&v, 4); };
+  k.clear();
+  put(C); put(o.su.blocksize0); put(o.su.blocksize1); put(o.su.num_floors); put(o.su.num_mappings); put(o.su.num_modes);
+  for (size_t i = 0; i < o.floors.size(); ++i) {
+    put(o.floors[i].multiplier);
+    put(o.floors[i].num_posts);
+    for (uint32_t x : o.xs[i]) put(x);
+  }
+  for (size_t m = 0; m < o.maps.size(); ++m) {
+    put(o.maps[m].num_couplings);
+    for (const vsyn_coupling& c : o.coup[m]) put(((uint32_t)c.magnitude << 16) | c.angle);
+    for (uint8_t f : o.chfloor[m]) put(f);
+  }
+  for (const vsyn_mode& m : o.modes) put(((uint32_t)m.block_flag << 8) | m.mapping);
+  return OkOrError();
+}
+
+static OkOrError make_synth(VorbisStream& st) {
+  SynthSetup ss;
+  CHECK_ERR(build_synth_setup(st, ss));
   const char* err = nullptr;
   int dev = 0;
   if (const char* e = getenv("PARSEOGGVORBIS_DEVICE")) dev = atoi(e);
-  const int rc = vsyn_create(&su, dev, 1, &st.synth_, &err);
+  const int rc = vsyn_create(&ss.su, dev, 1, &st.synth_, &err);
   if (rc != VSYN_OK) return OkOrError(std::string("GPU synthesis layer: ") + (err ? err : "vsyn_create failed"));
   CHECK(st.ys_stride_ == vsyn_ys_stride(st.synth_));
   return OkOrError();
@@ -670,6 +691,16 @@ static std::string status_text(const vsyn_status& st) {
 
 OkOrError VorbisStream::flush(ParseCallbacks& cb) {
   if (pk_.empty()) return OkOrError();
+  if (sink_) {  // somebody else runs the GPU (e.g. the corpus decoder merges many streams into one submit)
+    PacketBatch b;
+    b.pk.swap(pk_);
+    b.ys.swap(ys_);
+    b.residue.swap(residue_);
+    b.floor_number.swap(floor_number_);
+    b.first = first_batch_;
+    first_batch_ = false;
+    return sink_->consume(*this, std::move(b));
+  }
   if (!synth_) CHECK_ERR(make_synth(*this));  // the GPU handle is created when the first batch is ready
   const uint32_t C = header.audio_channels, P = (uint32_t)pk_.size();
   const uint32_t bs0 = header.get_blocksize_0(), bs1 = header.get_blocksize_1();
@@ -805,6 +836,9 @@ OkOrError OggReader::read_next_page(bool& reached_eof) {
   if (flags & HeaderFlag_First) {
     CHECK(streams_.find(serial) == streams_.end());
     streams_[serial].reset(new VorbisStream());
+    streams_[serial]->sink_ = sink_;
+    if (sink_) sink_->prepare(*streams_[serial]);
+    if (batch_limit_override_) streams_[serial]->batch_limit_ = batch_limit_override_;
   }
   auto it = streams_.find(serial);
   CHECK(it != streams_.end());

@@ -142,6 +142,26 @@ struct ParseCallbacks {  // returning false stops the read with a check failure,
   virtual bool gotEof() { return true; }
 };
 
+// What the entropy half leaves behind for a run of consecutive audio packets of one stream: exactly the tensors of the
+// C-ABI batch (include/vorbis_synth_hip.h).
+struct PacketBatch {
+  std::vector<vsyn_packet> pk;
+  std::vector<uint16_t> ys;            // [packet][channel][ys_stride]
+  std::vector<float> residue;          // packed [packet][channel][n/2]  ("after_residue")
+  std::vector<uint8_t> floor_number;   // [packet][channel], for the "floor_number" hook
+  bool first = true;                   // first batch of its stream (no overlap carry-in)
+};
+
+struct VorbisStream;
+// Where finished batches go. Default (nullptr): the stream's own GPU handle, synchronously, followed by the hook /
+// gotPcmData replay. The corpus decoder installs a collector instead and submits many files' batches in one GPU call.
+struct SynthSink {
+  virtual ~SynthSink() {}
+  virtual OkOrError consume(VorbisStream& stream, PacketBatch&& batch) = 0;
+  // called once when a stream is created: the sink may swap pre-reserved vectors into the stream's batch state
+  virtual void prepare(VorbisStream& stream) { (void)stream; }
+};
+
 // One logical Vorbis stream: headers, the per-stream GPU handle and the batch of entropy-decoded packets waiting for it.
 struct VorbisStream {
   VorbisIdHeader header;
@@ -160,6 +180,7 @@ struct VorbisStream {
   OkOrError flush(ParseCallbacks& cb);  // run the pending batch on the GPU and replay hooks + gotPcmData in packet order
 
   // --- batch state ---
+  SynthSink* sink_ = nullptr;
   vsyn_handle* synth_ = nullptr;
   uint32_t ys_stride_ = 0, batch_limit_ = 2048;
   bool first_batch_ = true;
@@ -176,6 +197,9 @@ struct OggReader {
   std::shared_ptr<IReader> reader_;
   ParseCallbacks& callbacks_;
 
+  SynthSink* sink_ = nullptr;           // optional: where streams hand their batches (see SynthSink)
+  uint32_t batch_limit_override_ = 0;   // optional: audio packets per batch (0: default / PARSEOGGVORBIS_BATCH)
+
   explicit OggReader(ParseCallbacks& callbacks) : packet_counts_(0), callbacks_(callbacks) {}
   OkOrError open_file(const std::string& filename);
   OkOrError set_reader(const std::shared_ptr<IReader>& reader);
@@ -184,6 +208,20 @@ struct OggReader {
   OkOrError full_read(const std::string& filename);
   OkOrError full_read_from_memory(const uint8_t* data, size_t data_len);
 };
+
+// The synthesis-relevant part of a stream's setup in C-ABI form (keeps the arrays the vsyn_setup points into alive), and
+// a byte string that is equal for two streams iff they can share one vsyn_handle.
+struct SynthSetup {
+  std::vector<vsyn_floor1> floors;
+  std::vector<std::vector<uint32_t>> xs;
+  std::vector<std::vector<vsyn_coupling>> coup;
+  std::vector<std::vector<uint8_t>> chfloor;
+  std::vector<vsyn_mapping> maps;
+  std::vector<vsyn_mode> modes;
+  vsyn_setup su;
+  std::string key;
+};
+OkOrError build_synth_setup(const VorbisStream& st, SynthSetup& out);
 
 extern "C" {
 // 0 on success; on failure 1 and *error_out (if non-NULL) points at a static, NUL-terminated 255-byte buffer

@@ -123,3 +123,28 @@ def test_hook_dump_format(built, tmp_path):
     assert len(entries[0][2]) == 0 and np.array_equal(entries[1][2], f) and np.array_equal(entries[2][2], u)
     assert entries[3][3] == 6 and int(entries[3][2][0]) == -1
     assert lib.generic_itoa(5, 2, 8) == b"00000101"
+
+
+CORPUS_CLI = os.path.join(HOST, "corpus_hip.bin")
+
+
+def test_corpus_entropy_workers_count_packets(built):
+    """Corpus front-end, workers only (no GPU involved): every replica of both fixtures is parsed, on several threads,
+    and the audio packet totals are those of the reference's decode (tests/golden)."""
+    import json
+    names = ["test.stereo44khz", "test.mono44khz"]
+    per = sum(len(load_golden(n)[1]["packets"]) for n in names)
+    r = subprocess.run([CORPUS_CLI, "--threads", "3", "--replicas", "5", "--entropy_only"] +
+                       [os.path.join(GOLDEN, n + ".ogg") for n in names], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["files"] == 10 and out["failed"] == 0 and out["submits"] == 0
+    assert out["audio_packets"] == 5 * per
+
+
+def test_corpus_fails_loudly_without_gpu(built):
+    if has_gpu():
+        pytest.skip("GPU present")
+    r = subprocess.run([CORPUS_CLI, "--threads", "2", "--replicas", "3", os.path.join(GOLDEN, "test.mono44khz.ogg")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and r.stdout == ""
