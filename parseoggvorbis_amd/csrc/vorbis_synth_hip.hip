@@ -518,14 +518,14 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   // staged kernels walk the work list the layout kernel built: everything when forced, otherwise only the runs the
   // fused kernel declines (short / mixed blocks, carry-in). In fused mode they run on a forked side stream beside the
   // fused kernel (disjoint outputs) and exit at once when the list is empty.
+  // With the mixed-block kernel available every run is taken by one of the two fused kernels (run_class() never answers
+  // 0 then; packets with an invalid mode are skipped by both paths): the staged kernels are not launched at all.
+  const bool staged_may_work = force_staged || !(h->fused_mask & 2u);
   hipStream_t ss = force_staged ? s : h->side;
-  if (!force_staged) HIPCHK(hipStreamWaitEvent(h->side, h->ev_pre_done[wb], 0));
-  {
-    // residue floats upper bound (the descriptors are device resident, so the exact sum is not known here). With the
-    // mixed-block kernel available the staged list can only hold packets with an invalid mode, which the staged kernels
-    // skip before touching these buffers: a token allocation is enough then.
-    const bool staged_may_work = force_staged || !(h->fused_mask & 2u);
-    const size_t bound = staged_may_work ? (size_t)P * C * (H.bs[1] / 2) : 64;
+  if (staged_may_work) {
+    if (!force_staged) HIPCHK(hipStreamWaitEvent(h->side, h->ev_pre_done[wb], 0));
+    // residue floats upper bound (the descriptors are device resident, so the exact sum is not known here)
+    const size_t bound = (size_t)P * C * (H.bs[1] / 2);
     float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
     float* blk = taps && taps->pcm_after_mdct ? taps->pcm_after_mdct : nullptr;
     if (!env) {
@@ -564,7 +564,7 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     a.R = R;
     a.fused_ok = h->fused_mask;
     a.coupling_mode = (uint32_t)h->fused.coupling_mode;
-    HIPCHK(hipEventRecord(h->ev_join, h->side));
+    if (staged_may_work) HIPCHK(hipEventRecord(h->ev_join, h->side));
     if (h->profile_which == 1) HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
     hipError_t e = fused_launch(H, h->fused, a, max_seg_packets, s);
     if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
@@ -578,7 +578,7 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
       if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused mixed launch failed: %s", hipGetErrorString(e));
       if (h->profile_which == 2) HIPCHK(profile_end(h, s));
     }
-    HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+    if (staged_may_work) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   }
   HIPCHK(hipEventRecord(h->ev_main_done[wb], s));
   h->main_done_valid[wb] = true;

@@ -130,13 +130,44 @@ __device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__
 // vmcnt(0).)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Pairwise hand-off between the two waves of a coupled channel pair, without involving the other waves of the workgroup
+// (an s_barrier puts all 8 waves in lockstep: they then stall on the same LDS / HBM phases together and the SIMDs idle).
+// Monotonic per-wave counters in LDS. LDS executes one wave's instructions in order, so `post` after a wave's data
+// accesses needs no wait, and a partner that has seen the counter sees (or no longer disturbs) that data.
+// (Explicit LDS address space: a volatile access through a generic pointer compiles to flat_load/flat_store, whose wait
+// also drains the vector-memory queue and with it the look-ahead residue loads.)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void pair_post(lds_u32* flag, uint32_t v) {
+  asm volatile("" ::: "memory");
+  *(volatile lds_u32*)flag = v;
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pair_wait(const lds_u32* flag, uint32_t v) {
+  asm volatile("" ::: "memory");
+  while (*(const volatile lds_u32*)flag < v) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+// v_min_f32 / v_max_f32 against 0 without the canonicalising v_max x,x the compiler adds in IEEE mode
+__device__ __forceinline__ float min0(float a) {
+  float r;
+  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ float max0(float a) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+// hpp:1220-1239 with one comparison per output: the a > 0 test folds into min(a,0) / max(a,0) (adding the resulting
+// +-0 returns the other operand unchanged), the m > 0 test picks the sign. Same single add per output, same value.
 __device__ __forceinline__ float couple_mag(float m, float a) {  // new magnitude-channel value
-  const float d = m > 0.f ? a : -a;
-  return a > 0.f ? m : m + d;
+  const float na = min0(a);
+  return m + (m > 0.f ? na : -na);
 }
 __device__ __forceinline__ float couple_ang(float m, float a) {  // new angle-channel value
-  const float d = m > 0.f ? a : -a;
-  return a > 0.f ? m - d : m;
+  const float pa = max0(a);
+  return m + (m > 0.f ? -pa : pa);
 }
 
 // The whole per-wave job: the run [qa, qb) of segment g, output channel c.
@@ -145,7 +176,7 @@ __device__ __forceinline__ float couple_ang(float m, float a) {  // new angle-ch
 // keeps only its own side of hpp:1219-1240 (5 VALU per bin instead of 7 for both).
 template <int ROLE>
 __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb, float4* __restrict__ seg,
-                                          const uint32_t lane0, const uint32_t g, const vsyn_segment sg, const SegInfo si,
+                                          lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane0, const uint32_t g, const vsyn_segment sg, const SegInfo si,
                                           const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c, const uint32_t pc) {
   constexpr uint32_t M = 1024;
   const uint8_t* __restrict__ cb = A.cb;
@@ -168,23 +199,18 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   PktInfo pi = A.info[sg.first_packet + q0];
   float2 raw[8];  // own channel's residue, requested one packet ahead
   {
-    const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M);
+    const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M) + lane0;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) raw[t] = src[lane0 + 64 * t];
+    for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
   }
   uint32_t lane_v = lane0;
-  // Every wave of the workgroup runs exactly R+1 iterations with two s_barriers each. The two waves of a coupled channel
-  // pair (adjacent waves, same run) each load ONLY their own channel from HBM and hand it to the partner through their
-  // exchange image, which is idle at that point: loading both channels in both waves costs a second HBM fetch of the
-  // whole input (measured: concurrent misses on a line are not merged; FETCH_SIZE x2 = 1.10 GB vs 0.55 GB per launch).
-  // Waves with fewer packets idle through the remaining barriers.
-  for (uint32_t it = 0; it <= A.R; ++it) {
+  // The two waves of a coupled channel pair (adjacent waves, same run, same packets) each load ONLY their own channel
+  // from HBM and hand it to the partner through their exchange image, which is idle at that point: loading both channels
+  // in both waves costs a second HBM fetch of the whole input (measured: concurrent misses on a line are not merged;
+  // FETCH_SIZE x2 = 1.10 GB vs 0.55 GB per launch). my_flags[0] = "my image holds packet #n's residue",
+  // my_flags[1] = "I have read the partner's image of packet #n".
+  for (uint32_t it = 0; q0 + it < qb; ++it) {
     const uint32_t q = q0 + it;
-    if (q >= qb) {
-      lds_barrier();
-      lds_barrier();
-      continue;
-    }
     // launder the lane id once per packet: keeps the lane-derived LDS/global addresses from being hoisted out of
     // the loop and pinned in VGPRs for its whole duration (recomputing them costs a few VALU ops)
     asm volatile("" : "+v"(lane_v));
@@ -202,8 +228,9 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     if (ROLE != 0) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
+      pair_post(&my_flags[0], it + 1);
+      pair_wait(&partner_flags[0], it + 1);  // both channels of the pair are in LDS
     }
-    lds_barrier();  // B1: both channels of the pair are in LDS
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (ROLE == 0) {
@@ -214,15 +241,15 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
                          : f2(couple_ang(oth.x, raw[t].x), couple_ang(oth.y, raw[t].y));
       }
     }
-    lds_barrier();  // B2: the partner has read this wave's image; it may be reused by the FFT below
+    if (ROLE != 0) pair_post(&my_flags[1], it + 1);
     // `raw` is dead: request packet q+1 now, so that its 4 KiB stay in flight behind this packet's floor product, FFT and
     // overlap (memory-level parallelism bounded this kernel, not occupancy). Unconditional on purpose: on a run's last
     // packet the current block is re-read (cache-resident, 1/R of the loads) — a `has_next` guard lets the compiler fold
     // these loads back into the loop header.
     {
-      const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * M);
+      const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * M) + lane;  // one 64-bit add, immediate offsets
 #pragma unroll
-      for (int t = 0; t < 8; ++t) raw[t] = src[lane + 64 * t];
+      for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -234,8 +261,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       float4 e;
       e.x = 0.f;
       e.y = 0.f;
-      e.z = 0.f;
-      e.w = ((pi.used >> c) & 1u) ? 4.f * 256.f : 4.f * 255.f;
+      e.z = __int_as_float(0);
+      e.w = __int_as_float(((pi.used >> c) & 1u) ? 4 * 256 : 4 * 255);
       seg[lane] = e;
     } else {
       const uint32_t f = mc->chfloor[c];
@@ -279,8 +306,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       float4 e;
       e.x = ady * inv;
       e.y = __builtin_fmaf(-ady, x0, 0.5f) * inv;
-      e.z = y1 >= y0 ? 4.f : -4.f;  // table index pre-scaled to a byte offset into invdb[]
-      e.w = 4.f * y0;
+      e.z = __int_as_float(y1 >= y0 ? 4 : -4);  // integers: table index pre-scaled to a byte offset into invdb[]
+      e.w = __int_as_float(4 * (int)y0);
       seg[lane] = e;
     }
     // coded posts of packet q+1, one packet ahead (valid if the floor does not change)
@@ -289,21 +316,29 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 
     // ---- floor curve at this lane's 16 bins + product (hpp:585-589, 1243-1255) -----------------------------
     // (a channel without a curve was given a constant x1.0 / x0.0 entry above: no branch here)
+    // Two dependent LDS look-ups per bin (segment entry, then inverse-dB value). Done four bins at a time so that a
+    // group's look-ups are in flight together: one exposed LDS round trip per group instead of one per bin.
     const float xf0 = (float)(2u * lane);
+    float fl[16];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float fl2[2];
+    for (int grp = 0; grp < 4; ++grp) {
+      float4 sgm[4];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int b = 2 * t + e;
-        const uint32_t sidx_b = (bseg[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-        const float4 sgm = seg[sidx_b];
-        const float qf = floorf(__builtin_fmaf(xf0 + (float)(128 * t + e), sgm.x, sgm.y));
-        const uint32_t byte_off = (uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w);  // 4 * index, index 0..255 between two posts <= 255
-        fl2[e] = *(const float*)((const char*)T.invdb + byte_off);
+      for (int i = 0; i < 4; ++i) {
+        const int b = 4 * grp + i;
+        sgm[i] = seg[(bseg[b >> 2] >> (8 * (b & 3))) & 0xFFu];
       }
-      r[t] = f2(r[t].x * fl2[0], r[t].y * fl2[1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int b = 4 * grp + i;
+        // x*A + B >= 0 between two posts, so the conversion's truncation is the floor (hpp:131-136)
+        const int qi = (int)(uint32_t)__builtin_fmaf(xf0 + (float)(128 * (b >> 1) + (b & 1)), sgm[i].x, sgm[i].y);
+        const int byte_off = __mul24(qi, __float_as_int(sgm[i].z)) + __float_as_int(sgm[i].w);  // 4 * index, 0..256
+        fl[b] = *(const float*)((const char*)T.invdb + byte_off);
+      }
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) r[t] = f2(r[t].x * fl[2 * t], r[t].y * fl[2 * t + 1]);
 
     // ---- IMDCT: mirror exchange, pre-rotation, FFT-512, post-rotation -------------------------------------
     float2 z[8];
@@ -312,6 +347,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       const float im = __shfl(r[7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
       z[t] = cmulf(f2(r[t].x, im), T.pre[t][lane]);
     }
+    if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT may reuse it
     fft512_wave(z, xb, &T, lane);
 #pragma unroll
     for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post[k][lane]);
@@ -329,28 +365,38 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     const uint32_t cur_next_long = (pi.widx >> 1) & 1u;
     float* out = A.pcm + ((size_t)g * C + c) * A.plane_stride + pi.out_pos;
     const bool fast_store = emit == M && (((uintptr_t)out & 7u) == 0);
+    float oh_s[4], oh_m[4], n_s[4], n_m[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int kh = 4 + j, kl = 3 - j;  // kh: even sample s = 2m-512 (own), kl: odd sample 511-2m (goes to the mirror lane)
       const float cch = z[kh].x, ccl = -z[kl].y;
-      const float oh_s = P[kh] * TR[1][kh][lane] + cch * TL[0][kh][lane];
-      const float oh_m = P[kh] * TR[0][kh][lane] + (-cch) * TL[1][kh][lane];
+      oh_s[j] = P[kh] * TR[1][kh][lane] + cch * TL[0][kh][lane];
+      oh_m[j] = P[kh] * TR[0][kh][lane] + (-cch) * TL[1][kh][lane];
       const float ol_s = P[kl] * TR[1][kl][lane] + ccl * TL[0][kl][lane];
       const float ol_m = P[kl] * TR[0][kl][lane] + (-ccl) * TL[1][kl][lane];
       P[kh] = z[kh].y;
       P[kl] = -z[kl].x;
       // partner point 511 - m of (this lane, kh) is (mirror lane, slot kl): it yields samples s+1 and 1022-s
-      const float n_s = __shfl(ol_s, 63 - (int)lane);
-      const float n_m = __shfl(ol_m, 63 - (int)lane);
-      const uint32_t s = 2u * (kappa + 64u * kh) - 512u;
-      if (fast_store) {
-        *(float2*)(out + s) = f2(oh_s, n_s);
-        *(float2*)(out + 1022u - s) = f2(n_m, oh_m);
-      } else if (emit) {
-        if (s < emit) out[s] = oh_s;
-        if (s + 1u < emit) out[s + 1u] = n_s;
-        if (1022u - s < emit) out[1022u - s] = n_m;
-        if (1023u - s < emit) out[1023u - s] = oh_m;
+      n_s[j] = __shfl(ol_s, 63 - (int)lane);
+      n_m[j] = __shfl(ol_m, 63 - (int)lane);
+    }
+    // sample s = 2*kappa + 128*j of (lane, kh = 4 + j): two lane pointers, every store at an immediate offset
+    if (fast_store) {
+      float* up = out + 2u * kappa;            // samples s, s+1
+      float* dn = out + 1022u - 2u * kappa;    // samples 1022-s, 1023-s
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *(float2*)(up + 128 * j) = f2(oh_s[j], n_s[j]);
+        *(float2*)(dn - 128 * j) = f2(n_m[j], oh_m[j]);
+      }
+    } else if (emit) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t s = 2u * kappa + 128u * j;
+        if (s < emit) out[s] = oh_s[j];
+        if (s + 1u < emit) out[s + 1u] = n_s[j];
+        if (1022u - s < emit) out[1022u - s] = n_m[j];
+        if (1023u - s < emit) out[1023u - s] = oh_m[j];
       }
     }
     if (q == num - 1) {  // stream carry for the next submit: windowed right half, natural order
@@ -377,6 +423,7 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   __shared__ FusedLdsImage s_t;
   __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
   __shared__ float4 s_seg[FUSED_WAVES][64];
+  __shared__ uint32_t s_flag[FUSED_WAVES][2];
   const ConstHeader* H = hdr_of(A.cb);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
@@ -395,19 +442,14 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
     const uint4* src = (const uint4*)A.lds_image;
     uint4* dst = (uint4*)&s_t;
     for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
+    if (threadIdx.x < FUSED_WAVES * 2) (&s_flag[0][0])[threadIdx.x] = 0u;
   }
-  __syncthreads();  // from here on waves only meet at the pair-sharing barriers inside the run loop
-  if (!active) {  // keep the workgroup's barrier count balanced
-    for (uint32_t it = 0; it <= A.R; ++it) {
-      lds_barrier();
-      lds_barrier();
-    }
-    return;
-  }
+  __syncthreads();  // the only workgroup-wide barrier: from here on a wave meets nobody but its coupling partner (pair_post/pair_wait)
+  if (!active) return;  // a run is active for all its channels or for none: no partner is left waiting
   const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
-  if (A.coupling_mode == 0 || C < 2) fused_run<0>(A, s_t, s_x[wave], s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, c);
-  else if (c == mag) fused_run<1>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, ang);
-  else fused_run<2>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, mag);
+  if (A.coupling_mode == 0 || C < 2) fused_run<0>(A, s_t, s_x[wave], s_x[wave], s_seg[wave], (lds_u32*)s_flag[wave], (const lds_u32*)s_flag[wave], lane, g, sg, si, qa, qb, C, c, c);
+  else if (c == mag) fused_run<1>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], (lds_u32*)s_flag[wave], (const lds_u32*)s_flag[wave ^ 1u], lane, g, sg, si, qa, qb, C, c, ang);
+  else fused_run<2>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], (lds_u32*)s_flag[wave], (const lds_u32*)s_flag[wave ^ 1u], lane, g, sg, si, qa, qb, C, c, mag);
 }
 
 // ================================================================================================

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""tools/pmc_summarize.py <dir> — fold the rocprofv3 CSVs written by tools/profile_round.sh into one JSON: per vsyn_* kernel the
+mean duration (kernel trace) and the mean of every counter per launch (counters are summed over the XCD/SE instances rocprofv3
+reports per dispatch)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+csv.field_size_limit(1 << 30)
+root = sys.argv[1]
+out = {"kernels": {}}
+for path in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(path)):
+        if row["Name"].startswith("vsyn_"):
+            k = out["kernels"].setdefault(row["Name"].split("(")[0], {})
+            k["calls"] = int(row["Calls"])
+            k["avg_ns"] = float(row["AverageNs"])
+            k["min_ns"] = float(row["MinNs"])
+            k["max_ns"] = float(row["MaxNs"])
+for path in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))  # (kernel, counter) -> dispatch -> value
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"].split("(")[0]
+        if name.startswith("vsyn_"):
+            per[(name, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    for (name, ctr), d in per.items():
+        vals = sorted(d.values())
+        out["kernels"].setdefault(name, {}).setdefault("pmc_mean_per_launch", {})[ctr] = sum(vals) / len(vals)
+lk = out["kernels"].get("vsyn_fused_long_kernel", {}).get("pmc_mean_per_launch", {})
+if "FETCH_SIZE" in lk and "WRITE_SIZE" in lk:
+    # KiB units; FETCH_SIZE counts half of the streamed bytes on gfx950 (MI355X_MICROARCH.md HBM section; tools/fetch_calib.hip)
+    out["long_kernel_hbm_bytes_per_launch"] = {"read_corrected": lk["FETCH_SIZE"] * 1024 * 2, "write": lk["WRITE_SIZE"] * 1024}
+print(json.dumps(out, indent=1, sort_keys=True))
