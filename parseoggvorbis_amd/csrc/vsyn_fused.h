@@ -170,6 +170,34 @@ __device__ __forceinline__ float couple_ang(float m, float a) {  // new angle-ch
   return m + (m > 0.f ? -pa : pa);
 }
 
+// Per-packet metadata through the scalar unit. Left to itself the compiler fetches PktInfo per lane and moves every
+// field to an SGPR with v_readfirstlane: it cannot prove that the PCM stores of the loop leave the array alone, so it
+// will not use s_load. Reading through the CONSTANT address space states exactly that (the layout kernel of an earlier
+// launch wrote the array; nothing writes it while this kernel runs) and turns a wave-uniform access into one
+// s_load_dwordx8 that the compiler schedules and waits for itself. Sub-dword fields are unpacked with scalar shifts
+// (there are no sub-dword scalar loads).
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+static_assert(sizeof(PktInfo) == 32, "PktInfo is fetched as one s_load_dwordx8");
+struct PktScalars {
+  uint64_t res_off;
+  uint32_t out_pos, emit, used, own, widx, mapping;
+};
+__device__ __forceinline__ PktScalars pkt_fields(const u32x8 r) {
+  PktScalars k;
+  k.res_off = (uint64_t)r[0] | ((uint64_t)r[1] << 32);
+  k.out_pos = r[2];
+  k.emit = r[3];
+  k.used = r[4];
+  k.own = r[5];
+  k.widx = r[6] >> 24;
+  k.mapping = r[7] & 0xFFu;
+  return k;
+}
+__device__ __forceinline__ PktScalars pkt_load(const PktInfo* p) {  // p wave-uniform
+  typedef const __attribute__((address_space(4))) u32x8* const_words;
+  return pkt_fields(*(const_words)(uintptr_t)p);
+}
+
 // The whole per-wave job: the run [qa, qb) of segment g, output channel c.
 // ROLE: 0 channel c is not coupled; 1 c is the magnitude channel of the (single) coupling step, `pc` its angle
 // partner; 2 c is the angle channel, `pc` the magnitude partner. A coupled wave loads both channels' residue and
@@ -195,8 +223,16 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   uint32_t vrow = 0;
   bool vrow_ok = false;
 
+  // loop-invariant header fields, read once (inside the loop they would be re-fetched per packet: the stores in between
+  // keep the compiler from hoisting them)
+  const uint32_t ys_stride = __builtin_amdgcn_readfirstlane(H->ys_stride);
+  const MapConst* const maps = (const MapConst*)(cb + H->off_map);
+  const FloorConst* const floors = (const FloorConst*)(cb + H->off_floor);
+  uint32_t cur_map = 0xFFFFFFFFu, map_floor = 0, posts = 0;
+
   const uint32_t q0 = qa ? qa - 1 : 0;
-  PktInfo pi = A.info[sg.first_packet + q0];
+  const PktInfo* const ip = A.info + __builtin_amdgcn_readfirstlane(sg.first_packet);
+  PktScalars pi = pkt_load(ip + q0);
   float2 raw[8];  // own channel's residue, requested one packet ahead
   {
     const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M) + lane0;
@@ -218,9 +254,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     const uint32_t kappa = ((lane & 7u) << 3) | (lane >> 3);
     const uint32_t p = sg.first_packet + q;
     const bool halo = q < qa, has_next = q + 1 < qb;
-    const MapConst* mc = map_of(cb, pi.mapping);
-    const PktInfo pin = A.info[has_next ? p + 1 : p];  // scalar loads, one packet ahead (never a struct select: that
-                                                       // would bounce through scratch memory)
+    const PktScalars pin = pkt_load(ip + (has_next ? q + 1 : q));  // one packet ahead
+    if (pi.mapping != cur_map) {  // wave-uniform, rare
+      cur_map = pi.mapping;
+      map_floor = __builtin_amdgcn_readfirstlane((uint32_t)maps[cur_map].chfloor[c]);
+    }
 
     // ---- residue: bins (2k, 2k+1), k = lane + 64 t (requested one packet ahead, see below); inverse coupling keeps
     //      this wave's side only (hpp:1213-1241) ----------------------------------------------------------------
@@ -255,28 +293,25 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 
     // ---- floor-1 step 2 set-up: one table entry per sorted-post interval (hpp:563-584) ---------------------
     bool floor_bad = false;
+    float2* const seg2 = (float2*)seg;  // this kernel's entries are 8 bytes: table index = floor(x * e.x + e.y)
     if (!((pi.own >> c) & 1u)) {
       // no curve of its own: one constant entry. Not used at all -> index 255 (table value exactly 1.0f, x*1 == x);
       // used through the coupling propagate -> index 256 (0.0f: floor_outputs stays zero, hpp:1159,1176-1179)
-      float4 e;
-      e.x = 0.f;
-      e.y = 0.f;
-      e.z = __int_as_float(0);
-      e.w = __int_as_float(((pi.used >> c) & 1u) ? 4 * 256 : 4 * 255);
-      seg[lane] = e;
+      seg2[lane] = f2(0.f, ((pi.used >> c) & 1u) ? 256.5f : 255.5f);
     } else {
-      const uint32_t f = mc->chfloor[c];
-      const FloorConst* fc = floor_of(cb, f);
-      const uint16_t* row = A.fy + ((size_t)p * C + c) * H->ys_stride;
+      const uint32_t f = map_floor;
+      const uint16_t* row = A.fy + ((size_t)p * C + c) * ys_stride;
       uint32_t v = vrow;
       if (cur_floor != (int)f) {  // wave-uniform, changes only when the mapping changes
+        const FloorConst* fc = floors + f;
+        posts = __builtin_amdgcn_readfirstlane(fc->posts);
         const uint8_t* bs = A.binseg + (size_t)f * M;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));
           if (t & 1) bseg[t >> 1] |= two << 16; else bseg[t >> 1] = two;
         }
-        const bool in = lane < fc->posts;
+        const bool in = lane < posts;
         sidx = in ? fc->sorted_idx[lane] : 0u;
         xsl = in ? fc->xs_sorted[lane] : 0u;
         cur_floor = (int)f;
@@ -284,7 +319,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       } else if (!vrow_ok) {
         v = row[sidx];
       }
-      if (lane >= fc->posts) v = 0;
+      if (lane >= posts) v = 0;
       const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
       const uint64_t below = mask & ((2ull << lane) - 1ull);  // flagged positions <= lane (bit 0 always set)
       const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
@@ -294,25 +329,23 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
       const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
       const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
-      // segment (x0,y0)-(x1,y1) in slope/intercept form: curve(x) = y0 + sgn * floor(x*A + B) with
-      // A = |dy|/adx, B = (0.5 - |dy| x0)/adx  ==  y0 +- (|dy| (x - x0)) / adx  in integers (Utils.hpp:122-137);
-      // the +0.5/adx guard band (>= 4.9e-4) dwarfs the f32 rounding of x*A + B (<= 6e-5 for x < 1024), DESIGN.md
+      // segment (x0,y0)-(x1,y1) in slope/intercept form: curve(x) = y0 + sgn * floor(u), u = x*A + B with
+      // A = |dy|/adx, B = (0.5 - |dy| x0)/adx  ==  y0 +- (|dy| (x - x0)) / adx  in integers (Utils.hpp:122-137).
+      // u is an odd multiple of 1/(2 adx), never an integer, so -floor(u) = floor(-u) + 1 and both directions fold into
+      //   curve(x) = floor(x * A' + B'),  rising: A' = A, B' = B + y0;  falling: A' = -A, B' = y0 + 1 - B
+      // (one fma + one conversion per bin, 8-byte entries). The 0.5/adx guard band dwarfs the f32 rounding, DESIGN.md
       floor_bad = (v & 0x7FFFu) > 255u;  // a post above 255 can only render >= 256 (hpp:587)
       const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
       const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
       // 1/adx: v_rcp_f32 (1 ulp) is enough — the guard band above leaves 8x headroom over the total rounding
       const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
       const float ady = fabsf(y1 - y0);
-      float4 e;
-      e.x = ady * inv;
-      e.y = __builtin_fmaf(-ady, x0, 0.5f) * inv;
-      e.z = __int_as_float(y1 >= y0 ? 4 : -4);  // integers: table index pre-scaled to a byte offset into invdb[]
-      e.w = __int_as_float(4 * (int)y0);
-      seg[lane] = e;
+      const float a = ady * inv, b = __builtin_fmaf(-ady, x0, 0.5f) * inv;
+      seg2[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);
     }
     // coded posts of packet q+1, one packet ahead (valid if the floor does not change)
     vrow_ok = has_next && pin.mapping == pi.mapping && cur_floor >= 0;
-    vrow = (A.fy + ((size_t)(has_next ? p + 1 : p) * C + c) * H->ys_stride)[sidx];
+    vrow = (A.fy + ((size_t)(has_next ? p + 1 : p) * C + c) * ys_stride)[sidx];
 
     // ---- floor curve at this lane's 16 bins + product (hpp:585-589, 1243-1255) -----------------------------
     // (a channel without a curve was given a constant x1.0 / x0.0 entry above: no branch here)
@@ -322,19 +355,17 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     float fl[16];
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
-      float4 sgm[4];
+      float2 sgm[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int b = 4 * grp + i;
-        sgm[i] = seg[(bseg[b >> 2] >> (8 * (b & 3))) & 0xFFu];
+        sgm[i] = seg2[(bseg[b >> 2] >> (8 * (b & 3))) & 0xFFu];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int b = 4 * grp + i;
-        // x*A + B >= 0 between two posts, so the conversion's truncation is the floor (hpp:131-136)
-        const int qi = (int)(uint32_t)__builtin_fmaf(xf0 + (float)(128 * (b >> 1) + (b & 1)), sgm[i].x, sgm[i].y);
-        const int byte_off = __mul24(qi, __float_as_int(sgm[i].z)) + __float_as_int(sgm[i].w);  // 4 * index, 0..256
-        fl[b] = *(const float*)((const char*)T.invdb + byte_off);
+        // the argument is positive (it exceeds a table index >= 0), so the conversion's truncation is the floor
+        fl[b] = T.invdb[(uint32_t)__builtin_fmaf(xf0 + (float)(128 * (b >> 1) + (b & 1)), sgm[i].x, sgm[i].y)];
       }
     }
 #pragma unroll
@@ -366,14 +397,35 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     float* out = A.pcm + ((size_t)g * C + c) * A.plane_stride + pi.out_pos;
     const bool fast_store = emit == M && (((uintptr_t)out & 7u) == 0);
     float oh_s[4], oh_m[4], n_s[4], n_m[4];
+    // window values of this lane's 8 points: left half of this block and mirrored right half of the previous one. Between
+    // two long blocks that is the same table (wave-uniform test): read it once.
+    float wl0[8], wl1[8], wr0[8], wr1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wl0[k] = TL[0][k][lane];
+      wl1[k] = TL[1][k][lane];
+    }
+    if (TR == TL) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        wr0[k] = wl0[k];
+        wr1[k] = wl1[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        wr0[k] = TR[0][k][lane];
+        wr1[k] = TR[1][k][lane];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int kh = 4 + j, kl = 3 - j;  // kh: even sample s = 2m-512 (own), kl: odd sample 511-2m (goes to the mirror lane)
       const float cch = z[kh].x, ccl = -z[kl].y;
-      oh_s[j] = P[kh] * TR[1][kh][lane] + cch * TL[0][kh][lane];
-      oh_m[j] = P[kh] * TR[0][kh][lane] + (-cch) * TL[1][kh][lane];
-      const float ol_s = P[kl] * TR[1][kl][lane] + ccl * TL[0][kl][lane];
-      const float ol_m = P[kl] * TR[0][kl][lane] + (-ccl) * TL[1][kl][lane];
+      oh_s[j] = P[kh] * wr1[kh] + cch * wl0[kh];
+      oh_m[j] = P[kh] * wr0[kh] + (-cch) * wl1[kh];
+      const float ol_s = P[kl] * wr1[kl] + ccl * wl0[kl];
+      const float ol_m = P[kl] * wr0[kl] + (-ccl) * wl1[kl];
       P[kh] = z[kh].y;
       P[kl] = -z[kl].x;
       // partner point 511 - m of (this lane, kh) is (mirror lane, slot kl): it yields samples s+1 and 1022-s
