@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VSYN_ABI_VERSION 1
+#define VSYN_ABI_VERSION 2 /* 2: + residue VQ stage (vsyn_attach_vq, vsyn_vq_batch), page-locked host buffers */
 
 #define VSYN_MAX_CHANNELS 32 /* floor_used is a 32-bit mask (reference: uint8_t audio_channels) */
 #define VSYN_MAX_POSTS 65    /* Vorbis I: 2 + 31 partitions x <=8 dims, capped at 65 by the spec */
@@ -51,7 +51,8 @@ enum {
   VSYN_ST_GRANULE = 1u << 2,       /* page granule behind/ahead of what the packets provide, hpp:1029,1041 */
   VSYN_ST_PLANE_OVERFLOW = 1u << 3,/* a segment emits more than plane_stride samples (nothing is written out of bounds) */
   VSYN_ST_BAD_MODE = 1u << 4,      /* mode index >= num_modes */
-  VSYN_ST_BAD_SEGMENT = 1u << 5    /* segment out of range / unknown stream slot / unaligned residue_off */
+  VSYN_ST_BAD_SEGMENT = 1u << 5,   /* segment out of range / unknown stream slot / unaligned residue_off */
+  VSYN_ST_BAD_VQ = 1u << 6         /* VQ stage: entry or classification number out of range, or entry count inconsistent with the classifications */
 };
 
 /* ---- stream setup: the part of VorbisStreamSetup (hpp:889-964) the synthesis half reads ---- */
@@ -169,6 +170,84 @@ int vsyn_submit_host(vsyn_handle* h,
                      float* pcm, uint64_t plane_stride,
                      uint32_t* emit_len, const vsyn_taps* taps,
                      uint32_t flags, vsyn_status* status, const char** err);
+
+/* ---- residue VQ stage: the data-parallel half of the residue decode on the device ----
+ *
+ * The reference's residue decode (VorbisResidue::decode, hpp:670-762) interleaves a bit-serial part — Huffman decode of
+ * one classification word per partition group and one codebook ENTRY NUMBER per vector (VorbisCodebook::decodeScalar,
+ * hpp:286-301) — with a data-parallel part: look the entry's value vector up (lookup_table_, hpp:212-245, 367-374) and
+ * add it into the residue vector (hpp:737-753), once per cascade pass, then de-interleave format 2 (hpp:687-693).
+ * With this stage the host decoder keeps only the bit-serial part and ships per packet the classifications (u8) and
+ * entry numbers (u16) instead of the expanded float vectors; the device rebuilds "after_residue" (hpp:1211) in the same
+ * order of additions, i.e. bit-identical, and the synthesis kernels continue from there.
+ */
+typedef struct vsyn_codebook {        /* VQ side of VorbisCodebook, hpp:104-245 */
+  uint32_t dimensions;                /* dimensions_ */
+  uint32_t num_entries;               /* num_entries_ (<= 65536 for this stage) */
+  const float* lookup;                /* lookup_table_: [num_entries][dimensions] value vectors, or NULL (lookup type 0: scalar-only book) */
+} vsyn_codebook;
+
+typedef struct vsyn_residue {         /* VorbisResidue, hpp:623-668 */
+  uint32_t type;                      /* 0, 1 or 2 */
+  uint32_t begin, end, partition_size;
+  uint32_t num_classifications;       /* 1..64 */
+  uint32_t classwords;                /* dimensions_ of the class codebook (classifications per codeword, hpp:703) */
+  const int16_t* books;               /* [num_classifications][8]: codebook per cascade pass, -1 = none (hpp:651-659) */
+} vsyn_residue;
+
+typedef struct vsyn_vq_mapping {      /* the residue side of VorbisMapping, hpp:765-814 */
+  uint32_t num_submaps;               /* 1..16 */
+  const uint8_t* mux;                 /* [channels]: submap of each channel (muxs) */
+  const uint8_t* submap_residue;      /* [num_submaps]: residue number of each submap */
+} vsyn_vq_mapping;
+
+typedef struct vsyn_vq_setup {
+  uint32_t num_codebooks; const vsyn_codebook* codebooks;
+  uint32_t num_residues;  const vsyn_residue* residues;
+  uint32_t num_mappings;  const vsyn_vq_mapping* mappings;   /* same count and order as vsyn_setup.mappings */
+} vsyn_vq_setup;
+
+/* Per packet, in decode order (hpp:708-760). For each submap s = 0.. of the packet's mapping, with the channels whose
+ * mux == s in channel order as j = 0..nch-1 (format 2: one virtual channel, always decoded, hpp:685-694):
+ *   cls      nch x parts bytes, [j][partition]: the classification numbers (hpp:716-719); parts = (min(end,len) -
+ *            min(begin,len)) / partition_size, len = n/2 (format 2: nch*n/2). Rows of unused channels are present, ignored.
+ *   entries  for pass 0..7, partition 0..parts-1, j 0..nch-1 (used channels with a codebook in that pass only):
+ *            partition_size / dimensions entry numbers (hpp:741, 749) */
+typedef struct vsyn_vq_packet {       /* 16 bytes */
+  uint64_t entry_off;                 /* index of the packet's first entry in entries[] */
+  uint32_t num_entries;
+  uint32_t cls_off;                   /* index of the packet's first byte in cls[] */
+} vsyn_vq_packet;
+
+typedef struct vsyn_vq_batch {        /* host or device pointers, like the other batch tensors of the call */
+  const vsyn_vq_packet* packets;      /* [P] */
+  const uint8_t* cls;
+  const uint16_t* entries;
+  uint64_t num_cls, num_entries;      /* array lengths (bounds for validation / staging) */
+} vsyn_vq_batch;
+
+/* Uploads the codebook value tables and residue descriptions. VSYN_ERR_INVALID (with the reason in *err) if the setup
+ * is outside what the stage handles — a book with more than 65536 entries, a vector length that does not divide the
+ * partition size, more than 8192 (pass, partition, channel) slots per packet; the caller then keeps feeding floats. */
+int vsyn_attach_vq(vsyn_handle* h, const vsyn_vq_setup* vq, const char** err);
+
+/* vsyn_submit_device / vsyn_submit_host with the residue given as VQ entries: `residue` becomes an OUTPUT of
+ * residue_floats floats (same packing as the input of vsyn_submit_*: it is the "after_residue" tensor; device scratch
+ * for vsyn_submit_device_vq, optional — may be NULL — copy-back for vsyn_submit_host_vq). Requires vsyn_attach_vq. */
+int vsyn_submit_device_vq(vsyn_handle* h,
+                          uint32_t num_packets, const vsyn_packet* d_packets,
+                          uint32_t num_segments, const vsyn_segment* d_segments, uint32_t max_seg_packets,
+                          const uint16_t* d_ys, const vsyn_vq_batch* d_vq, float* d_residue,
+                          float* d_pcm, uint64_t plane_stride,
+                          uint32_t* d_emit_len, const vsyn_taps* d_taps,
+                          uint32_t flags, void* hip_stream, const char** err);
+int vsyn_submit_host_vq(vsyn_handle* h,
+                        uint32_t num_packets, const vsyn_packet* packets,
+                        uint32_t num_segments, const vsyn_segment* segments,
+                        const uint16_t* ys, const vsyn_vq_batch* vq, float* residue_out, size_t residue_floats,
+                        float* pcm, uint64_t plane_stride,
+                        uint32_t* emit_len, const vsyn_taps* taps,
+                        uint32_t flags, vsyn_status* status, const char** err);
 
 /* Page-locked host memory for the buffers handed to vsyn_submit_host (direct DMA instead of the runtime's staging copies;
  * what a host decoder that batches at corpus scale wants). Pageable memory is accepted by vsyn_submit_host as well. */

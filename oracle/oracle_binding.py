@@ -15,7 +15,7 @@ REF_BIN = os.path.join(_HERE, "_ref", "ours.bin")
 
 import sys
 sys.path.insert(0, os.path.dirname(_HERE))
-from parseoggvorbis_amd.binding import (PACKET_DTYPE, SEGMENT_DTYPE, Setup, Status, Taps)  # POD layouts only
+from parseoggvorbis_amd.binding import (PACKET_DTYPE, SEGMENT_DTYPE, Setup, Status, Taps, VqSetup)  # POD layouts only
 
 _orc = None
 _ref = None
@@ -68,6 +68,7 @@ def oracle():
         lib.orc_reset_streams.argtypes = [vp]
         lib.orc_reset_streams.restype = None
         lib.orc_submit.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, u64, vp, C.POINTER(Taps), C.POINTER(Status)]
+        lib.orc_residue_vq.argtypes = [C.POINTER(VqSetup), u32, u32, u32, u32, vp, C.c_size_t, vp, C.c_size_t, vp]
         _orc = lib
     return _orc
 
@@ -155,3 +156,15 @@ def imdct(n, x):
     out = np.empty((x.shape[0], n), np.float32)
     oracle().orc_imdct_batch(n, x.shape[0], p(x), p(out))
     return out
+
+
+def residue_vq(vq_spec, mapping, channels, n2, used_mask, cls, entries):
+    """Oracle of the residue VQ accumulate stage for ONE packet -> (rc, float32 [channels*n2])."""
+    lib = oracle()
+    su = vq_spec.c_setup()
+    cls = np.ascontiguousarray(cls, np.uint8)
+    entries = np.ascontiguousarray(entries, np.uint16)
+    out = np.zeros(channels * n2, np.float32)
+    rc = lib.orc_residue_vq(C.byref(su), mapping, channels, n2, used_mask, cls.ctypes.data if cls.size else None, cls.size,
+                            entries.ctypes.data if entries.size else None, entries.size, out.ctypes.data)
+    return rc, out

@@ -671,3 +671,109 @@ int orc_submit(orc_handle* h, uint32_t num_packets, const vsyn_packet* packets, 
   }
   return status->flags ? VSYN_ERR_STREAM : VSYN_OK;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Residue VQ accumulate — follows VorbisResidue::decode, src/ParseOggVorbis.hpp:670-762, with the two
+ * bit-serial reads (class_codebook.decodeScalar hpp:714, vq_codebook.decodeVector hpp:742/750) replaced
+ * by the next number from cls[] / entries[]; decodeVector's table look-up is hpp:367-374
+ * (lookup_table_[entry * dimensions_ + l]).  The caller loop over submaps is VorbisStream::parse_audio,
+ * hpp:1184-1209.  Partition counter: advanced once per classword (Vorbis I 8.6.2), which is what the
+ * reference does for the 1-channel vectors of both fixtures; see DESIGN.md §7 for hpp:756.
+ * ------------------------------------------------------------------------------------------------ */
+static int orc_residue_vq_one(const vsyn_vq_setup* vq, const vsyn_residue* r, int type, uint32_t nch, const uint8_t* ch_used,
+                              uint32_t len, const uint8_t** cls_io, const uint8_t* cls_end, const uint16_t** ent_io,
+                              const uint16_t* ent_end, float* const* out) {
+  uint32_t lim_begin = r->begin < len ? r->begin : len; /* hpp:696-698 */
+  uint32_t lim_end = r->end < len ? r->end : len;
+  if (lim_begin > lim_end) return VSYN_ST_BAD_VQ;
+  uint32_t n_to_read = lim_end - lim_begin;
+  if (n_to_read == 0) return 0; /* hpp:705-706 */
+  uint32_t parts = n_to_read / r->partition_size; /* hpp:707 */
+  const uint8_t* cls = *cls_io;
+  if ((size_t)(cls_end - cls) < (size_t)nch * parts) return VSYN_ST_BAD_VQ;
+  *cls_io = cls + (size_t)nch * parts;
+  const uint16_t* ent = *ent_io;
+  for (int pass = 0; pass < 8; ++pass) {       /* hpp:711 */
+    for (uint32_t pc = 0; pc < parts; ++pc) {  /* hpp:713-759 without the bit reads */
+      for (uint32_t j = 0; j < nch; ++j) {
+        if (!ch_used[j]) continue;             /* hpp:729 */
+        uint32_t vq_class = cls[(size_t)j * parts + pc];
+        if (vq_class >= r->num_classifications) return VSYN_ST_BAD_VQ;
+        int book = r->books[vq_class * 8 + pass]; /* hpp:731 */
+        if (book < 0) continue;
+        if ((uint32_t)book >= vq->num_codebooks) return VSYN_ST_BAD_VQ;
+        const vsyn_codebook* cb = &vq->codebooks[book];
+        if (!cb->lookup || cb->dimensions == 0) return VSYN_ST_BAD_VQ; /* decodeVector on a scalar-only book fails, hpp:743 */
+        float* v = out[j];
+        uint32_t offset = lim_begin + pc * r->partition_size; /* hpp:735 */
+        if (type == 0) { /* 8.6.3, hpp:738-746 */
+          uint32_t step = r->partition_size / cb->dimensions;
+          for (uint32_t k = 0; k < step; ++k) {
+            if (ent >= ent_end || *ent >= cb->num_entries) return VSYN_ST_BAD_VQ;
+            const float* t = cb->lookup + (size_t)(*ent++) * cb->dimensions;
+            for (uint32_t l = 0; l < cb->dimensions; ++l) {
+              if (offset + k + l * step >= len) return VSYN_ST_BAD_VQ;
+              v[offset + k + l * step] += t[l];
+            }
+          }
+        } else { /* 8.6.4, hpp:747-754 */
+          for (uint32_t k = 0; k < r->partition_size;) {
+            if (ent >= ent_end || *ent >= cb->num_entries) return VSYN_ST_BAD_VQ;
+            const float* t = cb->lookup + (size_t)(*ent++) * cb->dimensions;
+            for (uint32_t l = 0; l < cb->dimensions; ++l, ++k) {
+              if (offset + k >= len) return VSYN_ST_BAD_VQ;
+              v[offset + k] += t[l];
+            }
+          }
+        }
+      }
+    }
+  }
+  *ent_io = ent;
+  return 0;
+}
+
+int orc_residue_vq(const vsyn_vq_setup* vq, uint32_t mapping, uint32_t channels, uint32_t n2, uint32_t used_mask,
+                   const uint8_t* cls, size_t num_cls, const uint16_t* entries, size_t num_entries, float* out) {
+  if (mapping >= vq->num_mappings || channels == 0 || channels > VSYN_MAX_CHANNELS) return VSYN_ST_BAD_VQ;
+  const vsyn_vq_mapping* mp = &vq->mappings[mapping];
+  const uint8_t* cls_end = cls + num_cls;
+  const uint16_t* ent = entries;
+  const uint16_t* ent_end = entries + num_entries;
+  memset(out, 0, sizeof(float) * (size_t)channels * n2); /* residue_outputs start at zero, hpp:1186-1190 */
+  for (uint32_t s = 0; s < mp->num_submaps; ++s) {        /* hpp:1184-1209 */
+    float* outs[VSYN_MAX_CHANNELS];
+    uint8_t used[VSYN_MAX_CHANNELS];
+    uint32_t chan[VSYN_MAX_CHANNELS];
+    uint32_t nch = 0;
+    for (uint32_t ch = 0; ch < channels; ++ch)
+      if (mp->mux[ch] == s) {
+        chan[nch] = ch;
+        outs[nch] = out + (size_t)ch * n2;
+        used[nch] = (uint8_t)((used_mask >> ch) & 1u);
+        ++nch;
+      }
+    if (nch == 0) continue;
+    if (mp->submap_residue[s] >= vq->num_residues) return VSYN_ST_BAD_VQ;
+    const vsyn_residue* r = &vq->residues[mp->submap_residue[s]];
+    int rc;
+    if (r->type == 2) { /* hpp:685-694: one interleaved vector decoded as format 1, always, then de-interleaved */
+      float* tmp = (float*)calloc((size_t)nch * n2, sizeof(float));
+      if (!tmp) return VSYN_ST_BAD_VQ;
+      uint8_t one = 1;
+      float* tv[1] = {tmp};
+      rc = orc_residue_vq_one(vq, r, 1, 1, &one, nch * n2, &cls, cls_end, &ent, ent_end, tv);
+      if (rc == 0)
+        for (uint32_t j = 0; j < nch; ++j)
+          for (uint32_t i = 0; i < n2; ++i) outs[j][i] = tmp[j + (size_t)nch * i];
+      free(tmp);
+    } else {
+      rc = orc_residue_vq_one(vq, r, (int)r->type, nch, used, n2, &cls, cls_end, &ent, ent_end, outs);
+    }
+    if (rc) return rc;
+    (void)chan;
+  }
+  if (ent != ent_end) return VSYN_ST_BAD_VQ; /* the packet's entry count must match what its classifications call for */
+  return 0;
+}

@@ -58,6 +58,14 @@ int orc_submit(orc_handle* h,
                float* pcm, uint64_t plane_stride,
                uint32_t* emit_len, const vsyn_taps* taps, vsyn_status* status);
 
+/* ---- residue VQ stage: the accumulate half of VorbisResidue::decode ----
+ * One packet: rebuilds "after_residue" (out: channels x n2 floats, channel-major) from the classifications and codebook
+ * entry numbers the bit-serial half left behind (layout: include/vorbis_synth_hip.h, vsyn_vq_packet).
+ * used_mask: floor_output_used after the nonzero propagate (hpp:1174-1180). Returns 0, or VSYN_ST_BAD_VQ when an entry /
+ * classification is out of range or the entry count does not match the classifications. */
+int orc_residue_vq(const vsyn_vq_setup* vq, uint32_t mapping, uint32_t channels, uint32_t n2, uint32_t used_mask,
+                   const uint8_t* cls, size_t num_cls, const uint16_t* entries, size_t num_entries, float* out);
+
 /* IMDCT only, for BASELINE config 2 and the cpu_baseline leg */
 void orc_imdct_batch(int n, uint32_t count, const float* in, float* out);
 

@@ -15,6 +15,7 @@ VSYN_MAX_CHANNELS = 32
 VSYN_MAX_POSTS = 65
 VSYN_OK, VSYN_ERR_INVALID, VSYN_ERR_NO_DEVICE, VSYN_ERR_HIP, VSYN_ERR_STREAM = 0, 1, 2, 3, 4
 VSYN_ST_FLOOR_RANGE, VSYN_ST_FLOOR_VALUE, VSYN_ST_GRANULE, VSYN_ST_PLANE_OVERFLOW, VSYN_ST_BAD_MODE = 1, 2, 4, 8, 16
+VSYN_ST_BAD_SEGMENT, VSYN_ST_BAD_VQ = 32, 64
 VSYN_SEG_RESET = 1
 VSYN_SUBMIT_STAGED = 1
 VSYN_SUBMIT_INPUTS_READY = 2
@@ -51,6 +52,70 @@ class Taps(C.Structure):
 class Status(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("first_bad_packet", C.c_uint32)]
 
+
+class Codebook(C.Structure):
+    _fields_ = [("dimensions", C.c_uint32), ("num_entries", C.c_uint32), ("lookup", C.POINTER(C.c_float))]
+
+
+class Residue(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("begin", C.c_uint32), ("end", C.c_uint32), ("partition_size", C.c_uint32),
+                ("num_classifications", C.c_uint32), ("classwords", C.c_uint32), ("books", C.POINTER(C.c_int16))]
+
+
+class VqMapping(C.Structure):
+    _fields_ = [("num_submaps", C.c_uint32), ("mux", C.POINTER(C.c_uint8)), ("submap_residue", C.POINTER(C.c_uint8))]
+
+
+class VqSetup(C.Structure):
+    _fields_ = [("num_codebooks", C.c_uint32), ("codebooks", C.POINTER(Codebook)),
+                ("num_residues", C.c_uint32), ("residues", C.POINTER(Residue)),
+                ("num_mappings", C.c_uint32), ("mappings", C.POINTER(VqMapping))]
+
+
+class VqBatch(C.Structure):
+    _fields_ = [("packets", C.c_void_p), ("cls", C.c_void_p), ("entries", C.c_void_p),
+                ("num_cls", C.c_uint64), ("num_entries", C.c_uint64)]
+
+
+class VqSpec:
+    """Plain-python description of the residue VQ setup; `.c_setup()` builds the vsyn_vq_setup tree (keeps it alive).
+    codebooks: list of (dimensions, num_entries, float32 table [entries*dims] or None)
+    residues:  list of dict(type, begin, end, partition_size, num_classifications, classwords, books int16 [nclass*8])
+    mappings:  list of (mux list [channels], submap_residue list)"""
+
+    def __init__(self, codebooks, residues, mappings):
+        self.codebooks, self.residues, self.mappings = codebooks, residues, mappings
+        self._keep = []
+
+    def c_setup(self):
+        keep = []
+        cb = (Codebook * len(self.codebooks))()
+        for i, (dims, n, tab) in enumerate(self.codebooks):
+            cb[i].dimensions, cb[i].num_entries = dims, n
+            if tab is not None:
+                t = np.ascontiguousarray(tab, np.float32)
+                keep.append(t)
+                cb[i].lookup = t.ctypes.data_as(C.POINTER(C.c_float))
+        rs = (Residue * len(self.residues))()
+        for i, r in enumerate(self.residues):
+            b = np.ascontiguousarray(r["books"], np.int16)
+            keep.append(b)
+            rs[i].type, rs[i].begin, rs[i].end, rs[i].partition_size = r["type"], r["begin"], r["end"], r["partition_size"]
+            rs[i].num_classifications, rs[i].classwords = r["num_classifications"], r["classwords"]
+            rs[i].books = b.ctypes.data_as(C.POINTER(C.c_int16))
+        mp = (VqMapping * len(self.mappings))()
+        for i, (mux, sres) in enumerate(self.mappings):
+            m = (C.c_uint8 * len(mux))(*mux)
+            sr = (C.c_uint8 * len(sres))(*sres)
+            keep += [m, sr]
+            mp[i].num_submaps, mp[i].mux, mp[i].submap_residue = len(sres), m, sr
+        keep += [cb, rs, mp]
+        self._keep.append(keep)
+        return VqSetup(len(self.codebooks), cb, len(self.residues), rs, len(self.mappings), mp)
+
+
+VQ_PACKET_DTYPE = np.dtype([("entry_off", "<u8"), ("num_entries", "<u4"), ("cls_off", "<u4")], align=True)
+assert VQ_PACKET_DTYPE.itemsize == 16
 
 # numpy record layouts of the batch PODs (sizes asserted against the header's comments)
 PACKET_DTYPE = np.dtype([("mode", "u1"), ("prev_long", "u1"), ("next_long", "u1"), ("reserved0", "u1"),
@@ -106,6 +171,7 @@ _SYMBOLS = [
     "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels",
     "vsyn_const_block_bytes", "vsyn_submit_device", "vsyn_submit_host", "vsyn_sync_status", "vsyn_reset_streams",
     "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device", "vsyn_host_alloc", "vsyn_host_free",
+    "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq",
 ]
 
 
@@ -151,6 +217,14 @@ def load():
     lib.vsyn_profile_enable.argtypes = [vp, C.c_int]
     lib.vsyn_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32), cpp]
     lib.vsyn_imdct_device.argtypes = [vp, u32, u32, vp, vp, vp, cpp]
+    lib.vsyn_attach_vq.argtypes = [vp, C.POINTER(VqSetup), cpp]
+    lib.vsyn_submit_device_vq.argtypes = [vp, u32, vp, u32, vp, u32, vp, C.POINTER(VqBatch), vp, vp, u64, vp,
+                                          C.POINTER(Taps), u32, vp, cpp]
+    lib.vsyn_submit_host_vq.argtypes = [vp, u32, vp, u32, vp, vp, C.POINTER(VqBatch), vp, C.c_size_t, vp, u64, vp,
+                                        C.POINTER(Taps), u32, C.POINTER(Status), cpp]
+    lib.vsyn_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp), cpp]
+    lib.vsyn_host_free.argtypes = [vp]
+    lib.vsyn_host_free.restype = None
     _lib = lib
     return lib
 
@@ -217,6 +291,48 @@ class Synth:
         if rc not in (VSYN_OK, VSYN_ERR_STREAM):
             raise VsynError(rc, (err.value or b"").decode())
         return dict(rc=rc, pcm=pcm, emit_len=emit, taps=taps, flags=st.flags, first_bad=st.first_bad_packet)
+
+    def attach_vq(self, vq_spec):
+        """vsyn_attach_vq: codebook value tables + residue descriptions for the device VQ stage."""
+        self._vq = vq_spec.c_setup()
+        err = C.c_char_p()
+        rc = self.lib.vsyn_attach_vq(self.h, C.byref(self._vq), C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
+
+    def submit_host_vq(self, packets, segments, ys, vq_packets, cls, entries, residue_floats, plane_stride,
+                       want_residue=True, flags=0):
+        """Like submit_host with the residue given as classification + entry numbers; returns 'residue' (the
+        rebuilt after_residue tensor) when want_residue."""
+        P, S, Cn = len(packets), len(segments), self.channels
+        packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
+        segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
+        ys = np.ascontiguousarray(ys, dtype=np.uint16)
+        vq_packets = np.ascontiguousarray(vq_packets, dtype=VQ_PACKET_DTYPE)
+        cls = np.ascontiguousarray(cls, dtype=np.uint8)
+        entries = np.ascontiguousarray(entries, dtype=np.uint16)
+        pcm = np.zeros((S, Cn, plane_stride), np.float32)
+        emit = np.zeros(P, np.uint32)
+        res = np.zeros(residue_floats, np.float32) if want_residue else None
+        vb = VqBatch(vq_packets.ctypes.data, cls.ctypes.data if cls.size else None,
+                     entries.ctypes.data if entries.size else None, cls.size, entries.size)
+        st, err = Status(), C.c_char_p()
+        rc = self.lib.vsyn_submit_host_vq(self.h, P, _ptr(packets), S, _ptr(segments), _ptr(ys), C.byref(vb), _ptr(res),
+                                          residue_floats, _ptr(pcm), plane_stride, _ptr(emit), None, flags,
+                                          C.byref(st), C.byref(err))
+        if rc not in (VSYN_OK, VSYN_ERR_STREAM):
+            raise VsynError(rc, (err.value or b"").decode())
+        return dict(rc=rc, pcm=pcm, emit_len=emit, residue=res, flags=st.flags, first_bad=st.first_bad_packet)
+
+    def submit_device_vq(self, P, d_packets, S, d_segments, max_seg_packets, d_ys, d_vq_packets, d_cls, num_cls, d_entries,
+                         num_entries, d_residue, d_pcm, plane_stride, d_emit=None, flags=0, stream=None):
+        """All pointers are raw device addresses (ints)."""
+        err = C.c_char_p()
+        vb = VqBatch(d_vq_packets, d_cls, d_entries, num_cls, num_entries)
+        rc = self.lib.vsyn_submit_device_vq(self.h, P, d_packets, S, d_segments, max_seg_packets, d_ys, C.byref(vb),
+                                            d_residue, d_pcm, plane_stride, d_emit, None, flags, stream, C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
 
     def submit_device(self, P, d_packets, S, d_segments, max_seg_packets, d_ys, d_residue, d_pcm, plane_stride,
                       d_emit=None, taps=None, flags=0, stream=None):

@@ -21,6 +21,7 @@
 #include "vsyn_device.h"
 #include "vsyn_staged.h"
 #include "vsyn_fused.h"
+#include "vsyn_vq.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846264338327
@@ -89,6 +90,11 @@ struct vsyn_handle {
   ConstHeader H{};
   std::vector<uint8_t> host_const;
   uint8_t* d_const = nullptr;
+  uint8_t* d_vq = nullptr;             // residue VQ stage: VqHeader, books, residues, maps, value pool (vsyn_attach_vq)
+  uint32_t vq_max_slots = 0;
+  DevBuf<vsyn_vq_packet> st_vqpk;      // vsyn_submit_host_vq staging
+  DevBuf<uint8_t> st_cls;
+  DevBuf<uint16_t> st_ent;
   StreamState* d_state = nullptr;
   float* d_carry = nullptr;
   DevStatus* d_status = nullptr;
@@ -370,6 +376,8 @@ void vsyn_destroy(vsyn_handle* h) {
     if (h->ev_main_done[b]) (void)hipEventDestroy(h->ev_main_done[b]);
   }
   if (h->d_const) (void)hipFree(h->d_const);
+  if (h->d_vq) (void)hipFree(h->d_vq);
+  h->st_vqpk.release(); h->st_cls.release(); h->st_ent.release();
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_carry) (void)hipFree(h->d_carry);
   if (h->d_status) (void)hipFree(h->d_status);
@@ -461,13 +469,19 @@ int vsyn_sync_status(vsyn_handle* h, void* hip_stream, vsyn_status* status, cons
   return VSYN_OK;
 }
 
-int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets, uint32_t S, const vsyn_segment* d_segments,
-                       uint32_t max_seg_packets, const uint16_t* d_ys, const float* d_residue, float* d_pcm,
-                       uint64_t plane_stride, uint32_t* d_emit_len, const vsyn_taps* taps, uint32_t flags, void* hip_stream,
-                       const char** err) {
+// d_vq == nullptr: d_residue is the input ("after_residue"). Otherwise d_residue is scratch that the residue VQ kernel
+// fills from the entry numbers (after the layout kernel, which provides each packet's offset, beside the floor unwrap).
+static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets, uint32_t S, const vsyn_segment* d_segments,
+                              uint32_t max_seg_packets, const uint16_t* d_ys, const vsyn_vq_batch* d_vq, float* d_residue, float* d_pcm,
+                              uint64_t plane_stride, uint32_t* d_emit_len, const vsyn_taps* taps, uint32_t flags, void* hip_stream,
+                              const char** err) {
   if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
   if (P == 0 || S == 0) return VSYN_OK;
   if (!d_packets || !d_segments || !d_ys || !d_residue || !d_pcm) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
+  if (d_vq) {
+    if (!h->d_vq) return fail(err, VSYN_ERR_INVALID, "vsyn_attach_vq has not been called on this handle");
+    if (!d_vq->packets || (d_vq->num_cls && !d_vq->cls) || (d_vq->num_entries && !d_vq->entries)) return fail(err, VSYN_ERR_INVALID, "NULL vq batch pointer");
+  }
   if (max_seg_packets == 0 || max_seg_packets > P) max_seg_packets = P;
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHK(hipSetDevice(h->device));
@@ -512,6 +526,10 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
     vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,
                                                                                                        d_ys, fy, h->d_status);
   }
+  if (d_vq)
+    vsyn_residue_vq_kernel<<<P, VQ_THREADS, (size_t)h->vq_max_slots * sizeof(uint32_t), ps>>>(h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls,
+                                                                                              d_vq->num_cls, d_vq->entries, d_vq->num_entries,
+                                                                                              d_residue, h->d_status);
   HIPCHK(hipEventRecord(h->ev_pre_done[wb], ps));
   if (ps != s) HIPCHK(hipStreamWaitEvent(s, h->ev_pre_done[wb], 0));
 
@@ -586,16 +604,59 @@ int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets,
   return VSYN_OK;
 }
 
-int vsyn_submit_host(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uint32_t S, const vsyn_segment* segments,
-                     const uint16_t* ys, const float* residue, size_t residue_floats, float* pcm, uint64_t plane_stride,
-                     uint32_t* emit_len, const vsyn_taps* taps, uint32_t flags, vsyn_status* status, const char** err) {
+int vsyn_submit_device(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets, uint32_t S, const vsyn_segment* d_segments,
+                       uint32_t max_seg_packets, const uint16_t* d_ys, const float* d_residue, float* d_pcm,
+                       uint64_t plane_stride, uint32_t* d_emit_len, const vsyn_taps* taps, uint32_t flags, void* hip_stream,
+                       const char** err) {
+  return submit_device_impl(h, P, d_packets, S, d_segments, max_seg_packets, d_ys, nullptr, const_cast<float*>(d_residue), d_pcm, plane_stride,
+                            d_emit_len, taps, flags, hip_stream, err);
+}
+
+int vsyn_submit_device_vq(vsyn_handle* h, uint32_t P, const vsyn_packet* d_packets, uint32_t S, const vsyn_segment* d_segments,
+                          uint32_t max_seg_packets, const uint16_t* d_ys, const vsyn_vq_batch* d_vq, float* d_residue, float* d_pcm,
+                          uint64_t plane_stride, uint32_t* d_emit_len, const vsyn_taps* taps, uint32_t flags, void* hip_stream,
+                          const char** err) {
+  if (!d_vq) return fail(err, VSYN_ERR_INVALID, "vq batch is NULL");
+  return submit_device_impl(h, P, d_packets, S, d_segments, max_seg_packets, d_ys, d_vq, d_residue, d_pcm, plane_stride, d_emit_len, taps, flags,
+                            hip_stream, err);
+}
+
+int vsyn_attach_vq(vsyn_handle* h, const vsyn_vq_setup* vq, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  std::vector<uint8_t> block;
+  const std::string why = vq_build_block(vq, h->H, block);
+  if (!why.empty()) return fail(err, VSYN_ERR_INVALID, "%s", why.c_str());
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());  // a previously attached block may still be in use
+  if (h->d_vq) (void)hipFree(h->d_vq);
+  h->d_vq = nullptr;
+  HIPCHK(hipMalloc((void**)&h->d_vq, block.size()));
+  HIPCHK(hipMemcpy(h->d_vq, block.data(), block.size(), hipMemcpyHostToDevice));
+  h->vq_max_slots = ((const VqHeader*)block.data())->max_slots;
+  return VSYN_OK;
+}
+
+// residue != nullptr: floats in. Otherwise vq != nullptr: entry numbers in, floats rebuilt on the device and optionally
+// copied back to residue_out.
+static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uint32_t S, const vsyn_segment* segments,
+                            const uint16_t* ys, const float* residue, const vsyn_vq_batch* vq, float* residue_out, size_t residue_floats,
+                            float* pcm, uint64_t plane_stride, uint32_t* emit_len, const vsyn_taps* taps, uint32_t flags, vsyn_status* status,
+                            const char** err) {
   if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
   if (status) {
     status->flags = 0;
     status->first_bad_packet = 0xFFFFFFFFu;
   }
   if (P == 0 || S == 0) return VSYN_OK;
-  if (!packets || !segments || !ys || !residue || !pcm) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
+  if (!packets || !segments || !ys || (!residue && !vq) || !pcm) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
+  if (vq) {
+    if (!h->d_vq) return fail(err, VSYN_ERR_INVALID, "vsyn_attach_vq has not been called on this handle");
+    if (!vq->packets || (vq->num_cls && !vq->cls) || (vq->num_entries && !vq->entries)) return fail(err, VSYN_ERR_INVALID, "NULL vq batch pointer");
+    for (uint32_t p = 0; p < P; ++p)
+      if (vq->packets[p].entry_off + vq->packets[p].num_entries > vq->num_entries || vq->packets[p].cls_off > vq->num_cls)
+        return fail(err, VSYN_ERR_INVALID, "vq packet %u points outside the entry / classification arrays", p);
+  }
   const ConstHeader& H = h->H;
   const uint32_t C = H.channels;
   // host-visible validation (the device re-checks everything it dereferences)
@@ -640,15 +701,31 @@ int vsyn_submit_host(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uin
   HIPCHK(hipMemcpyAsync(h->st_pk.p, packets, sizeof(vsyn_packet) * P, hipMemcpyHostToDevice, hs));
   HIPCHK(hipMemcpyAsync(h->st_seg.p, segments, sizeof(vsyn_segment) * S, hipMemcpyHostToDevice, hs));
   HIPCHK(hipMemcpyAsync(h->st_ys.p, ys, sizeof(uint16_t) * ys_n, hipMemcpyHostToDevice, hs));
-  HIPCHK(hipMemcpyAsync(h->st_res.p, residue, sizeof(float) * residue_floats, hipMemcpyHostToDevice, hs));
+  vsyn_vq_batch dvq;
+  if (vq) {
+    HIPCHK(h->st_vqpk.ensure(P));
+    HIPCHK(h->st_cls.ensure((size_t)vq->num_cls + 16));
+    HIPCHK(h->st_ent.ensure((size_t)vq->num_entries + 16));
+    HIPCHK(hipMemcpyAsync(h->st_vqpk.p, vq->packets, sizeof(vsyn_vq_packet) * P, hipMemcpyHostToDevice, hs));
+    if (vq->num_cls) HIPCHK(hipMemcpyAsync(h->st_cls.p, vq->cls, (size_t)vq->num_cls, hipMemcpyHostToDevice, hs));
+    if (vq->num_entries) HIPCHK(hipMemcpyAsync(h->st_ent.p, vq->entries, sizeof(uint16_t) * (size_t)vq->num_entries, hipMemcpyHostToDevice, hs));
+    dvq.packets = h->st_vqpk.p;
+    dvq.cls = h->st_cls.p;
+    dvq.entries = h->st_ent.p;
+    dvq.num_cls = vq->num_cls;
+    dvq.num_entries = vq->num_entries;
+  } else {
+    HIPCHK(hipMemcpyAsync(h->st_res.p, residue, sizeof(float) * residue_floats, hipMemcpyHostToDevice, hs));
+  }
   HIPCHK(hipMemsetAsync(h->st_pcm.p, 0, sizeof(float) * pcm_n, hs));
   if (dt.floor_final) HIPCHK(hipMemsetAsync(h->st_fy.p, 0, ys_n * sizeof(uint16_t), hs));
   if (dt.after_envelope) HIPCHK(hipMemsetAsync(dt.after_envelope, 0, sizeof(float) * residue_floats, hs));
   if (dt.pcm_after_mdct) HIPCHK(hipMemsetAsync(dt.pcm_after_mdct, 0, sizeof(float) * 2 * residue_floats, hs));
   const bool any_tap = dt.after_envelope || dt.pcm_after_mdct || dt.floor_final;
-  int rc = vsyn_submit_device(h, P, h->st_pk.p, S, h->st_seg.p, max_seg, h->st_ys.p, h->st_res.p, h->st_pcm.p, plane_stride,
-                              h->st_emit.p, any_tap ? &dt : nullptr, flags, hs, err);
+  int rc = submit_device_impl(h, P, h->st_pk.p, S, h->st_seg.p, max_seg, h->st_ys.p, vq ? &dvq : nullptr, h->st_res.p, h->st_pcm.p, plane_stride,
+                              h->st_emit.p, any_tap ? &dt : nullptr, flags & ~VSYN_SUBMIT_INPUTS_READY, hs, err);
   if (rc) return rc;
+  if (vq && residue_out) HIPCHK(hipMemcpyAsync(residue_out, h->st_res.p, sizeof(float) * residue_floats, hipMemcpyDeviceToHost, hs));
   // results are queued behind the kernels before the one host wait
   HIPCHK(hipMemcpyAsync(pcm, h->st_pcm.p, sizeof(float) * pcm_n, hipMemcpyDeviceToHost, hs));
   if (emit_len) HIPCHK(hipMemcpyAsync(emit_len, h->st_emit.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, hs));
@@ -659,6 +736,23 @@ int vsyn_submit_host(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uin
   rc = vsyn_sync_status(h, hs, &st, err);
   if (status) *status = st;
   return rc;
+}
+
+int vsyn_submit_host(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uint32_t S, const vsyn_segment* segments,
+                     const uint16_t* ys, const float* residue, size_t residue_floats, float* pcm, uint64_t plane_stride,
+                     uint32_t* emit_len, const vsyn_taps* taps, uint32_t flags, vsyn_status* status, const char** err) {
+  if (!residue && P && S) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
+  return submit_host_impl(h, P, packets, S, segments, ys, residue, nullptr, nullptr, residue_floats, pcm, plane_stride, emit_len, taps, flags, status,
+                          err);
+}
+
+int vsyn_submit_host_vq(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, uint32_t S, const vsyn_segment* segments,
+                        const uint16_t* ys, const vsyn_vq_batch* vq, float* residue_out, size_t residue_floats, float* pcm,
+                        uint64_t plane_stride, uint32_t* emit_len, const vsyn_taps* taps, uint32_t flags, vsyn_status* status,
+                        const char** err) {
+  if (!vq && P && S) return fail(err, VSYN_ERR_INVALID, "vq batch is NULL");
+  return submit_host_impl(h, P, packets, S, segments, ys, nullptr, vq, residue_out, residue_floats, pcm, plane_stride, emit_len, taps, flags, status,
+                          err);
 }
 
 int vsyn_host_alloc(size_t bytes, void** out, const char** err) {

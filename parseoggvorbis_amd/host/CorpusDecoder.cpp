@@ -23,6 +23,11 @@ struct FileRecord {
     batch.ys.clear();
     batch.residue.clear();
     batch.floor_number.clear();
+    batch.vq_pk.clear();
+    batch.cls.clear();
+    batch.entries.clear();
+    batch.vq = false;
+    batch.residue_floats = 0;
     batch.first = true;
     ys_stride = 0;
     has_audio = false;
@@ -49,6 +54,9 @@ struct CollectSink : SynthSink {
     st.ys_.swap(rec.batch.ys);
     st.residue_.swap(rec.batch.residue);
     st.floor_number_.swap(rec.batch.floor_number);
+    st.vq_pk_.swap(rec.batch.vq_pk);
+    st.cls_.swap(rec.batch.cls);
+    st.entries_.swap(rec.batch.entries);
   }
   OkOrError consume(VorbisStream& st, PacketBatch&& b) override {
     if (owner && owner != &st) return OkOrError("corpus path: files with more than one logical Vorbis stream are not supported");
@@ -171,6 +179,10 @@ struct Group {
   PinnedArray<uint16_t> ys;
   PinnedArray<float> residue, pcm;
   PinnedArray<uint32_t> emit;
+  bool vq = false;  // files of this group ship classification + entry numbers instead of residue floats
+  PinnedArray<vsyn_vq_packet> vq_pk;
+  PinnedArray<uint8_t> cls;
+  PinnedArray<uint16_t> entries;
   ~Group() {
     if (handle) vsyn_destroy(handle);
   }
@@ -212,27 +224,51 @@ struct Feeder {
     if (g.pending.empty()) return OkOrError();
     const uint32_t C = g.channels, S = (uint32_t)g.pending.size();
     double t0 = now_s();
-    size_t P = 0, rfloats = 0;
+    size_t P = 0, rfloats = 0, ncls = 0, nent = 0;
     uint32_t max_p = 0;
     for (const auto& r : g.pending) {
       P += r->batch.pk.size();
-      rfloats += r->batch.residue.size();
+      rfloats += r->batch.residue_floats;
+      ncls += r->batch.cls.size();
+      nent += r->batch.entries.size();
       max_p = std::max<uint32_t>(max_p, (uint32_t)r->batch.pk.size());
     }
+    CHECK(ncls < 0xffffffffu);
     CHECK(P < 0xffffffffu);
     const uint64_t plane = (uint64_t)max_p * (g.bs1 / 2);
     CHECK_ERR(g.pk.ensure(P));
     CHECK_ERR(g.seg.ensure(S));
     CHECK_ERR(g.ys.ensure(P * C * g.ys_stride));
-    CHECK_ERR(g.residue.ensure(rfloats));
+    if (g.vq) {
+      CHECK_ERR(g.vq_pk.ensure(P));
+      CHECK_ERR(g.cls.ensure(ncls));
+      CHECK_ERR(g.entries.ensure(nent));
+    } else {
+      CHECK_ERR(g.residue.ensure(rfloats));
+    }
     CHECK_ERR(g.emit.ensure(P));
     CHECK_ERR(g.pcm.ensure((size_t)S * C * plane));
-    size_t p0 = 0, r0 = 0;
+    size_t p0 = 0, r0 = 0, c0 = 0, e0 = 0;
     for (uint32_t s = 0; s < S; ++s) {
       const PacketBatch& b = g.pending[s]->batch;
+      CHECK(b.vq == g.vq);
       memcpy(&g.pk[p0], b.pk.data(), b.pk.size() * sizeof(vsyn_packet));
       memcpy(&g.ys[p0 * C * g.ys_stride], b.ys.data(), b.ys.size() * sizeof(uint16_t));
-      memcpy(&g.residue[r0], b.residue.data(), b.residue.size() * sizeof(float));
+      if (g.vq) {
+        CHECK(b.vq_pk.size() == b.pk.size());
+        for (size_t q = 0; q < b.vq_pk.size(); ++q) {  // rebase the file's offsets into the merged arrays
+          vsyn_vq_packet v = b.vq_pk[q];
+          v.entry_off += e0;
+          v.cls_off += (uint32_t)c0;
+          g.vq_pk[p0 + q] = v;
+        }
+        memcpy(&g.cls[c0], b.cls.data(), b.cls.size());
+        memcpy(&g.entries[e0], b.entries.data(), b.entries.size() * sizeof(uint16_t));
+        c0 += b.cls.size();
+        e0 += b.entries.size();
+      } else {
+        memcpy(&g.residue[r0], b.residue.data(), b.residue.size() * sizeof(float));
+      }
       vsyn_segment& sg = g.seg[s];
       memset(&sg, 0, sizeof(sg));
       sg.stream = s;
@@ -241,14 +277,24 @@ struct Feeder {
       sg.flags = VSYN_SEG_RESET;
       sg.residue_off = r0;
       p0 += b.pk.size();
-      r0 += b.residue.size();
+      r0 += b.residue_floats;
     }
     double t1 = now_s();
     stats.pack_s += t1 - t0;
     vsyn_status st = {0, 0xffffffffu};
     const char* err = nullptr;
-    int rc = vsyn_submit_host(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, g.residue.p, rfloats, g.pcm.p, plane, g.emit.p, nullptr, 0, &st,
-                              &err);
+    int rc;
+    if (g.vq) {
+      vsyn_vq_batch vqb;
+      vqb.packets = g.vq_pk.p;
+      vqb.cls = g.cls.p;
+      vqb.entries = g.entries.p;
+      vqb.num_cls = ncls;
+      vqb.num_entries = nent;
+      rc = vsyn_submit_host_vq(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, &vqb, nullptr, rfloats, g.pcm.p, plane, g.emit.p, nullptr, 0, &st, &err);
+    } else {
+      rc = vsyn_submit_host(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, g.residue.p, rfloats, g.pcm.p, plane, g.emit.p, nullptr, 0, &st, &err);
+    }
     double t2 = now_s();
     stats.gpu_call_s += t2 - t1;
     stats.submits++;
@@ -340,6 +386,12 @@ struct Feeder {
         stats.files++;
         return OkOrError();
       }
+      if (rec->synth.has_vq && vsyn_attach_vq(gp->handle, &rec->synth.vq, &err) != VSYN_OK) {
+        std::string msg = std::string("GPU synthesis layer: ") + (err ? err : "vsyn_attach_vq failed");
+        groups.erase(rec->synth.key);
+        return OkOrError(msg);
+      }
+      gp->vq = rec->synth.has_vq;
       gp->channels = rec->header.audio_channels;
       gp->bs1 = rec->header.get_blocksize_1();
       gp->ys_stride = vsyn_ys_stride(gp->handle);

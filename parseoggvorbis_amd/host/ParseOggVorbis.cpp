@@ -372,6 +372,56 @@ OkOrError VorbisResidue::decode(BitReader& reader, const std::vector<VorbisCodeb
   return OkOrError();
 }
 
+// Same control flow as decode() above with the table look-up and the adds left out: what remains is the bit-serial half.
+OkOrError VorbisResidue::decode_entries(BitReader& reader, const std::vector<VorbisCodebook>& codebooks, uint32_t num_channel,
+                                        const std::vector<bool>& channel_used, uint32_t decode_len, std::vector<uint8_t>& cls_out,
+                                        std::vector<uint16_t>& entries_out, int type_override) const {
+  const int type = type_override >= 0 ? type_override : (int)this->type;
+  CHECK(num_channel > 0 && channel_used.size() == num_channel);
+  if (type == 2) return decode_entries(reader, codebooks, 1, std::vector<bool>{true}, num_channel * decode_len, cls_out, entries_out, 1);
+  const uint32_t lim_begin = std::min(begin, decode_len), lim_end = std::min(end, decode_len);
+  CHECK(lim_begin <= lim_end);
+  const VorbisCodebook& cbook = codebooks[classbook];
+  const uint32_t cw = cbook.dimensions_;
+  const uint32_t n_to_read = lim_end - lim_begin;
+  if (!n_to_read) return OkOrError();
+  const uint32_t parts = n_to_read / partition_size;
+  const uint32_t per_ch = parts + cw;
+  std::vector<uint8_t> cls((size_t)num_channel * per_ch, 0);
+  for (int pass = 0; pass < 8; ++pass) {
+    uint32_t pc = 0;
+    while (pc < parts) {
+      if (pass == 0)
+        for (uint32_t j = 0; j < num_channel; ++j) {
+          if (!channel_used[j]) continue;
+          uint32_t temp = cbook.decodeScalar(reader);
+          for (uint32_t i = cw; i > 0; --i) {
+            cls[(size_t)j * per_ch + (i - 1) + pc] = (uint8_t)(temp % num_classifications);
+            temp /= num_classifications;
+          }
+        }
+      for (uint32_t i = 0; i < cw && pc < parts; ++i, ++pc) {
+        for (uint32_t j = 0; j < num_channel; ++j) {
+          if (!channel_used[j]) continue;
+          const int book = books[(size_t)cls[(size_t)j * per_ch + pc] * 8 + (size_t)pass];
+          if (book < 0) continue;
+          const VorbisCodebook& vq = codebooks[(size_t)book];
+          CHECK(vq.lookup_type_ != 0);  // decodeVector on a scalar-only book
+          const uint32_t count = partition_size / vq.dimensions_;  // stream_can_use_vq: dimensions_ divides partition_size
+          CHECK(lim_begin + (pc + 1) * partition_size <= decode_len);
+          for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t e = vq.decodeScalar(reader);
+            CHECK(e < vq.num_entries_);
+            entries_out.push_back((uint16_t)e);
+          }
+        }
+      }
+    }
+  }
+  for (uint32_t j = 0; j < num_channel; ++j) cls_out.insert(cls_out.end(), cls.begin() + (size_t)j * per_ch, cls.begin() + (size_t)j * per_ch + parts);
+  return OkOrError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // mappings, modes, setup (4.2.4)
 // ------------------------------------------------------------------------------------------------
@@ -531,8 +581,42 @@ OkOrError VorbisStream::parse_setup(const uint8_t* data, uint32_t len, ParseCall
       if (f.floor_type == 1) maxp = std::max(maxp, f.floor1.xs.size());
     ys_stride_ = (uint32_t)((maxp + 3) & ~(size_t)3);
   }
+  vq_mode_ = stream_can_use_vq(*this);
+  setup_hash_ = 1469598103934665603ull;
+  for (uint32_t i = 0; i < len; ++i) setup_hash_ = (setup_hash_ ^ data[i]) * 1099511628211ull;
   CHECK(cb.gotSetup(setup));
   return OkOrError();
+}
+
+// Whether the residue may leave the host as entry numbers: the limits of vsyn_attach_vq, checked on the host model.
+bool stream_can_use_vq(const VorbisStream& st) {
+  if (const char* e = getenv("PARSEOGGVORBIS_VQ"))
+    if (e[0] == '0') return false;
+  const uint32_t C = st.header.audio_channels, n2max = st.header.get_blocksize_1() / 2u;
+  for (const VorbisResidue& r : st.setup.residues) {
+    if (r.type > 2 || r.partition_size == 0 || r.num_classifications > 64) return false;
+    if (r.classbook >= st.setup.codebooks.size() || st.setup.codebooks[r.classbook].dimensions_ == 0) return false;
+    for (size_t i = 0; i < r.books.size(); ++i) {
+      const int b = r.books[i];
+      if (b < 0) continue;
+      if ((size_t)b >= st.setup.codebooks.size()) return false;
+      const VorbisCodebook& cb = st.setup.codebooks[(size_t)b];
+      if (!cb.lookup_type_ || cb.dimensions_ == 0 || cb.num_entries_ > 65536u) return false;
+      if (r.partition_size % cb.dimensions_) return false;
+    }
+  }
+  for (const VorbisMapping& mp : st.setup.mappings)
+    for (size_t s = 0; s < mp.submaps.size(); ++s) {
+      uint32_t nch = 0;
+      for (uint32_t ch = 0; ch < C; ++ch) nch += mp.muxs[ch] == s;
+      if (!nch) continue;
+      if (mp.submaps[s].residue >= st.setup.residues.size()) return false;
+      const VorbisResidue& r = st.setup.residues[mp.submaps[s].residue];
+      const uint32_t len = r.type == 2 ? nch * n2max : n2max, vch = r.type == 2 ? 1u : nch;
+      const uint32_t parts = (std::min(r.end, len) - std::min(r.begin, len)) / r.partition_size;
+      if ((uint64_t)8 * parts * vch > 8192u) return false;
+    }
+  return true;
 }
 
 // The synthesis-relevant part of the setup, handed to the GPU layer once per stream (or once per group of streams that
@@ -591,6 +675,56 @@ OkOrError build_synth_setup(const VorbisStream& st, SynthSetup& o) {
     for (uint8_t f : o.chfloor[m]) put(f);
   }
   for (const vsyn_mode& m : o.modes) put(((uint32_t)m.block_flag << 8) | m.mapping);
+
+  // residue VQ stage: codebook value tables (copied: the setup outlives the stream in the corpus decoder), residue
+  // descriptions, channel -> submap -> residue
+  o.has_vq = st.vq_mode_;
+  if (o.has_vq) {
+    o.books.resize(st.setup.codebooks.size());
+    o.book_tables.resize(st.setup.codebooks.size());
+    for (size_t i = 0; i < o.books.size(); ++i) {
+      const VorbisCodebook& cb = st.setup.codebooks[i];
+      o.books[i].dimensions = cb.dimensions_;
+      o.books[i].num_entries = cb.num_entries_;
+      if (cb.lookup_type_ && !cb.lookup_table_.empty()) o.book_tables[i] = cb.lookup_table_;
+      o.books[i].lookup = o.book_tables[i].empty() ? nullptr : o.book_tables[i].data();
+    }
+    o.residues.resize(st.setup.residues.size());
+    o.residue_books.resize(st.setup.residues.size());
+    for (size_t i = 0; i < o.residues.size(); ++i) {
+      const VorbisResidue& r = st.setup.residues[i];
+      o.residue_books[i].assign(r.books.begin(), r.books.end());
+      o.residues[i].type = r.type;
+      o.residues[i].begin = r.begin;
+      o.residues[i].end = r.end;
+      o.residues[i].partition_size = r.partition_size;
+      o.residues[i].num_classifications = r.num_classifications;
+      o.residues[i].classwords = st.setup.codebooks[r.classbook].dimensions_;
+      o.residues[i].books = o.residue_books[i].data();
+    }
+    o.vq_maps.resize(st.setup.mappings.size());
+    o.mux.resize(st.setup.mappings.size());
+    o.submap_residue.resize(st.setup.mappings.size());
+    for (size_t m = 0; m < o.vq_maps.size(); ++m) {
+      const VorbisMapping& mp = st.setup.mappings[m];
+      o.mux[m].assign(mp.muxs.begin(), mp.muxs.end());
+      for (const VorbisMapping::Submap& sm : mp.submaps) o.submap_residue[m].push_back(sm.residue);
+      o.vq_maps[m].num_submaps = (uint32_t)mp.submaps.size();
+      o.vq_maps[m].mux = o.mux[m].data();
+      o.vq_maps[m].submap_residue = o.submap_residue[m].data();
+    }
+    o.vq.num_codebooks = (uint32_t)o.books.size();
+    o.vq.codebooks = o.books.data();
+    o.vq.num_residues = (uint32_t)o.residues.size();
+    o.vq.residues = o.residues.data();
+    o.vq.num_mappings = (uint32_t)o.vq_maps.size();
+    o.vq.mappings = o.vq_maps.data();
+    // the key covers codebooks and residues through the hash of the setup header packet that defined them
+    const uint64_t hsh = st.setup_hash_;
+    put(0x56515631u);  // "VQV1"
+    put((uint32_t)hsh);
+    put((uint32_t)(hsh >> 32));
+  }
   return OkOrError();
 }
 
@@ -603,6 +737,8 @@ static OkOrError make_synth(VorbisStream& st) {
   const int rc = vsyn_create(&ss.su, dev, 1, &st.synth_, &err);
   if (rc != VSYN_OK) return OkOrError(std::string("GPU synthesis layer: ") + (err ? err : "vsyn_create failed"));
   CHECK(st.ys_stride_ == vsyn_ys_stride(st.synth_));
+  if (ss.has_vq && vsyn_attach_vq(st.synth_, &ss.vq, &err) != VSYN_OK)
+    return OkOrError(std::string("GPU synthesis layer: ") + (err ? err : "vsyn_attach_vq failed"));
   return OkOrError();
 }
 
@@ -650,21 +786,36 @@ OkOrError VorbisStream::parse_audio(const uint8_t* data, uint32_t len, int64_t g
   for (const VorbisMapping::Coupling& c : mapping.couplings)
     if (used[(size_t)c.angle] || used[(size_t)c.magintude]) used[(size_t)c.angle] = used[(size_t)c.magintude] = true;
 
-  // 4.3.4 residue decode straight into the batch buffer ("after_residue")
+  // 4.3.4 residue decode: straight into the batch buffer ("after_residue"), or — VQ mode — only its bit-serial half:
+  // classification and entry numbers; the device looks the vectors up and adds them
   const size_t res0 = residue_.size();
-  residue_.resize(res0 + (size_t)C * n2, 0.f);
+  vsyn_vq_packet vqp;
+  memset(&vqp, 0, sizeof(vqp));
+  if (vq_mode_) {
+    vqp.entry_off = entries_.size();
+    CHECK(cls_.size() < 0xffffffffu);
+    vqp.cls_off = (uint32_t)cls_.size();
+  } else {
+    residue_.resize(res0 + (size_t)C * n2, 0.f);
+  }
   for (size_t s = 0; s < mapping.submaps.size(); ++s) {
     std::vector<float*> outs;
     std::vector<bool> ch_used;
     for (uint32_t ch = 0; ch < C; ++ch)
       if (mapping.muxs[ch] == s) {
-        outs.push_back(&residue_[res0 + (size_t)ch * n2]);
+        outs.push_back(vq_mode_ ? nullptr : &residue_[res0 + (size_t)ch * n2]);
         ch_used.push_back(used[ch]);
       }
     if (outs.empty()) continue;
     const VorbisResidue& res = setup.residues[mapping.submaps[s].residue];
-    CHECK_ERR(res.decode(reader, setup.codebooks, (uint32_t)outs.size(), ch_used, n2, outs.data()));
+    if (vq_mode_) CHECK_ERR(res.decode_entries(reader, setup.codebooks, (uint32_t)outs.size(), ch_used, n2, cls_, entries_));
+    else CHECK_ERR(res.decode(reader, setup.codebooks, (uint32_t)outs.size(), ch_used, n2, outs.data()));
   }
+  if (vq_mode_) {
+    vqp.num_entries = (uint32_t)(entries_.size() - vqp.entry_off);
+    vq_pk_.push_back(vqp);
+  }
+  residue_floats_ += (size_t)C * n2;
 
   vsyn_packet pk;
   memset(&pk, 0, sizeof(pk));
@@ -686,6 +837,7 @@ static std::string status_text(const vsyn_status& st) {
   if (st.flags & VSYN_ST_PLANE_OVERFLOW) s += " pcm plane overflow";
   if (st.flags & VSYN_ST_BAD_MODE) s += " bad mode";
   if (st.flags & VSYN_ST_BAD_SEGMENT) s += " bad segment";
+  if (st.flags & VSYN_ST_BAD_VQ) s += " residue entry / classification number out of range";
   return s;
 }
 
@@ -697,6 +849,12 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
     b.ys.swap(ys_);
     b.residue.swap(residue_);
     b.floor_number.swap(floor_number_);
+    b.vq = vq_mode_;
+    b.vq_pk.swap(vq_pk_);
+    b.cls.swap(cls_);
+    b.entries.swap(entries_);
+    b.residue_floats = residue_floats_;
+    residue_floats_ = 0;
     b.first = first_batch_;
     first_batch_ = false;
     return sink_->consume(*this, std::move(b));
@@ -711,9 +869,10 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
   std::vector<float> env, blk;
   std::vector<uint16_t> ffin;
   vsyn_taps taps = {nullptr, nullptr, nullptr};
+  if (vq_mode_ && hooks) residue_.assign(residue_floats_, 0.f);  // the "after_residue" hook needs the floats back from the device
   if (hooks) {
-    env.resize(residue_.size());
-    blk.resize(residue_.size() * 2);
+    env.resize(residue_floats_);
+    blk.resize(residue_floats_ * 2);
     ffin.resize(ys_.size());
     taps.after_envelope = env.data();
     taps.pcm_after_mdct = blk.data();
@@ -728,8 +887,20 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
   seg.residue_off = 0;
   vsyn_status st = {0, 0xffffffffu};
   const char* err = nullptr;
-  const int rc = vsyn_submit_host(synth_, P, pk_.data(), 1, &seg, ys_.data(), residue_.data(), residue_.size(), pcm.data(), plane, emit.data(),
-                                  hooks ? &taps : nullptr, 0, &st, &err);
+  int rc;
+  if (vq_mode_) {
+    vsyn_vq_batch vqb;
+    vqb.packets = vq_pk_.data();
+    vqb.cls = cls_.data();
+    vqb.entries = entries_.data();
+    vqb.num_cls = cls_.size();
+    vqb.num_entries = entries_.size();
+    rc = vsyn_submit_host_vq(synth_, P, pk_.data(), 1, &seg, ys_.data(), &vqb, hooks ? residue_.data() : nullptr, residue_floats_, pcm.data(), plane,
+                             emit.data(), hooks ? &taps : nullptr, 0, &st, &err);
+  } else {
+    rc = vsyn_submit_host(synth_, P, pk_.data(), 1, &seg, ys_.data(), residue_.data(), residue_.size(), pcm.data(), plane, emit.data(),
+                          hooks ? &taps : nullptr, 0, &st, &err);
+  }
   if (rc != VSYN_OK && rc != VSYN_ERR_STREAM) return OkOrError(std::string("GPU synthesis layer: ") + (err ? err : "submit failed"));
   const uint32_t good = rc == VSYN_ERR_STREAM ? std::min(P, st.first_bad_packet) : P;
 
@@ -786,6 +957,10 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
   ys_.clear();
   residue_.clear();
   floor_number_.clear();
+  vq_pk_.clear();
+  cls_.clear();
+  entries_.clear();
+  residue_floats_ = 0;
   first_batch_ = false;
   if (rc == VSYN_ERR_STREAM) return OkOrError(status_text(st));
   return OkOrError();

@@ -104,6 +104,11 @@ struct VorbisResidue {  // Vorbis I 8.6
   // out: num_channel vectors of decode_len floats, zero-initialised by the caller; adds the VQ vectors (8.6.2-8.6.5)
   OkOrError decode(BitReader& reader, const std::vector<VorbisCodebook>& codebooks, uint32_t num_channel, const std::vector<bool>& channel_used,
                    uint32_t decode_len, float* const* out, int type_override = -1) const;
+  // bit-serial half only (for the device VQ stage, include/vorbis_synth_hip.h): appends the classification numbers
+  // ([channel][partition]) and, in decode order, the codebook entry numbers; no value vector is looked up or added
+  OkOrError decode_entries(BitReader& reader, const std::vector<VorbisCodebook>& codebooks, uint32_t num_channel,
+                           const std::vector<bool>& channel_used, uint32_t decode_len, std::vector<uint8_t>& cls_out,
+                           std::vector<uint16_t>& entries_out, int type_override = -1) const;
 };
 
 struct VorbisMapping {
@@ -147,8 +152,14 @@ struct ParseCallbacks {  // returning false stops the read with a check failure,
 struct PacketBatch {
   std::vector<vsyn_packet> pk;
   std::vector<uint16_t> ys;            // [packet][channel][ys_stride]
-  std::vector<float> residue;          // packed [packet][channel][n/2]  ("after_residue")
+  std::vector<float> residue;          // packed [packet][channel][n/2]  ("after_residue"); empty in VQ mode
   std::vector<uint8_t> floor_number;   // [packet][channel], for the "floor_number" hook
+  // VQ mode (the device rebuilds "after_residue" from these):
+  bool vq = false;
+  std::vector<vsyn_vq_packet> vq_pk;
+  std::vector<uint8_t> cls;
+  std::vector<uint16_t> entries;
+  size_t residue_floats = 0;           // what `residue` would hold
   bool first = true;                   // first batch of its stream (no overlap carry-in)
 };
 
@@ -189,6 +200,14 @@ struct VorbisStream {
   std::vector<uint16_t> ys_;
   std::vector<float> residue_;
   std::vector<uint8_t> floor_number_;  // [packet][channel], for the "floor_number" hook
+  // VQ mode: the residue leaves the host as classification + entry numbers (decided once per stream in parse_setup:
+  // every VQ book <= 65536 entries, vector lengths dividing the partition sizes; PARSEOGGVORBIS_VQ=0 turns it off)
+  bool vq_mode_ = false;
+  uint64_t setup_hash_ = 0;  // FNV-1a of the setup header packet: identifies the codebooks when streams share a handle
+  std::vector<vsyn_vq_packet> vq_pk_;
+  std::vector<uint8_t> cls_;
+  std::vector<uint16_t> entries_;
+  size_t residue_floats_ = 0;
 };
 
 struct OggReader {
@@ -220,8 +239,18 @@ struct SynthSetup {
   std::vector<vsyn_mode> modes;
   vsyn_setup su;
   std::string key;
+  // residue VQ stage (filled when the stream can use it; `key` then also covers the codebook tables)
+  bool has_vq = false;
+  std::vector<vsyn_codebook> books;
+  std::vector<std::vector<float>> book_tables;  // owned copies: the setup must be usable after the stream is gone
+  std::vector<vsyn_residue> residues;
+  std::vector<std::vector<int16_t>> residue_books;
+  std::vector<vsyn_vq_mapping> vq_maps;
+  std::vector<std::vector<uint8_t>> mux, submap_residue;
+  vsyn_vq_setup vq;
 };
 OkOrError build_synth_setup(const VorbisStream& st, SynthSetup& out);
+bool stream_can_use_vq(const VorbisStream& st);  // the conditions of vsyn_attach_vq, checked on the host model
 
 extern "C" {
 // 0 on success; on failure 1 and *error_out (if non-NULL) points at a static, NUL-terminated 255-byte buffer

@@ -1,0 +1,159 @@
+"""GPU: the residue VQ stage (include/vorbis_synth_hip.h "residue VQ stage").  The kernel rebuilds
+'after_residue' from classification + entry numbers; checked bit-exactly against (a) the reference decoder's own
+'after_residue' dumps for both fixtures (tests/golden), with the PCM of the whole path behind it, and (b) the oracle's
+restatement of hpp:725-757 on random well-formed entry streams, plus the error reporting."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle_binding as ob
+from parseoggvorbis_amd.binding import (PACKET_DTYPE, SEGMENT_DTYPE, VQ_PACKET_DTYPE, VSYN_ERR_STREAM, VSYN_SEG_RESET,
+                                        VSYN_ST_BAD_VQ, Synth, VsynError, VqSpec)
+from tests.workloads import GOLDEN, build_probe, load_golden, read_entropy_dump, synth_vq_packet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    return build_probe(tmp_path_factory.mktemp("probe"))
+
+
+def _dump(probe, name, tmp_path):
+    out = str(tmp_path / (name + ".bin"))
+    r = subprocess.run([probe, os.path.join(GOLDEN, name + ".ogg"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return read_entropy_dump(out)
+
+
+def _propagated(spec, mode, own):
+    used = int(own)
+    for mag, ang in spec.mappings[spec.modes[mode][1]][0]:
+        if (used >> mag) & 1 or (used >> ang) & 1:
+            used |= (1 << mag) | (1 << ang)
+    return used
+
+
+@pytest.mark.parametrize("name", ["test.stereo44khz", "test.mono44khz"])
+def test_vq_stage_reproduces_reference_residue_and_pcm(probe, name, tmp_path):
+    spec, b, _ = load_golden(name)
+    d = _dump(probe, name, tmp_path)
+    P = d["P"]
+    syn = Synth(spec, max_streams=1)
+    syn.attach_vq(d["vq_spec"])
+    seg = np.zeros(1, SEGMENT_DTYPE)
+    seg[0] = (0, 0, P, VSYN_SEG_RESET, 0)
+    out = syn.submit_host_vq(d["packets"], seg, d["ys"], d["vq_packets"], d["cls"], d["entries"], d["residue_floats"],
+                             P * spec.blocksize1 // 2)
+    assert out["rc"] == 0 and out["flags"] == 0
+    assert np.array_equal(out["residue"].view(np.uint32), b["residue"].view(np.uint32))  # == reference 'after_residue'
+    total = b["pcm"].shape[1]
+    assert int(out["emit_len"].sum()) == total
+    assert np.abs(out["pcm"][0][:, :total] - b["pcm"]).max() < TOL
+    # same batch cut into two submits (overlap carried on the device) gives the same PCM
+    syn.reset()
+    cut = 41
+    got = []
+    for lo, hi, flag in ((0, cut, VSYN_SEG_RESET), (cut, P, 0)):
+        sg = np.zeros(1, SEGMENT_DTYPE)
+        sg[0] = (0, 0, hi - lo, flag, 0)
+        vqp = d["vq_packets"][lo:hi].copy()
+        c0 = int(vqp["cls_off"][0])
+        e0 = int(vqp["entry_off"][0])
+        c1 = int(d["vq_packets"]["cls_off"][hi]) if hi < P else d["cls"].size
+        e1 = int(d["vq_packets"]["entry_off"][hi]) if hi < P else d["entries"].size
+        vqp["cls_off"] -= c0
+        vqp["entry_off"] -= e0
+        n_of = [spec.blocksize_of_mode(int(m)) // 2 * spec.channels for m in d["packets"]["mode"][lo:hi]]
+        o = syn.submit_host_vq(d["packets"][lo:hi], sg, d["ys"][lo:hi], vqp, d["cls"][c0:c1], d["entries"][e0:e1], int(sum(n_of)),
+                               (hi - lo) * spec.blocksize1 // 2, want_residue=False)
+        assert o["rc"] == 0
+        got.append(o["pcm"][0][:, :int(o["emit_len"].sum())])
+    assert np.abs(np.concatenate(got, axis=1) - b["pcm"]).max() < TOL
+
+
+def _random_vq_batch(spec, vq_spec, streams, per_stream, pattern, seed):
+    rng = np.random.default_rng(seed)
+    Cn = spec.channels
+    long_mode = [i for i, (bf, _) in enumerate(spec.modes) if bf][0]
+    short_mode = [i for i, (bf, _) in enumerate(spec.modes) if not bf][0]
+    P = streams * per_stream
+    pk = np.zeros(P, PACKET_DTYPE)
+    vqp = np.zeros(P, VQ_PACKET_DTYPE)
+    seg = np.zeros(streams, SEGMENT_DTYPE)
+    cls_l, ent_l, want = [], [], []
+    c_off = e_off = r_off = 0
+    for s in range(streams):
+        seg[s] = (s, s * per_stream, per_stream, VSYN_SEG_RESET, r_off)
+        for q in range(per_stream):
+            p = s * per_stream + q
+            lng = pattern[q % len(pattern)]
+            mode = long_mode if lng else short_mode
+            pk[p]["mode"], pk[p]["prev_long"], pk[p]["next_long"], pk[p]["granule"] = mode, 1, 1, -1
+            if lng:
+                pk[p]["prev_long"] = pattern[(q - 1) % len(pattern)] if q else 1
+                pk[p]["next_long"] = pattern[(q + 1) % len(pattern)] if q + 1 < per_stream else 1
+            own = int(rng.integers(0, 1 << Cn)) if rng.random() < 0.3 else (1 << Cn) - 1
+            pk[p]["floor_used"] = own  # ys stay zero: a flat floor; this test is about the residue
+            n2 = spec.blocksize_of_mode(mode) // 2
+            used = _propagated(spec, mode, own)
+            cls, ent = synth_vq_packet(vq_spec, spec.modes[mode][1], Cn, n2, used, rng)
+            rc, res = ob.residue_vq(vq_spec, spec.modes[mode][1], Cn, n2, used, cls, ent)
+            assert rc == 0
+            vqp[p] = (e_off, ent.size, c_off)
+            cls_l.append(cls)
+            ent_l.append(ent)
+            want.append(res)
+            c_off += cls.size
+            e_off += ent.size
+            r_off += Cn * n2
+    return pk, seg, vqp, np.concatenate(cls_l), np.concatenate(ent_l), np.concatenate(want)
+
+
+@pytest.mark.parametrize("name,pattern", [("test.stereo44khz", [1]), ("test.stereo44khz", [1, 1, 0, 0, 0, 1]), ("test.mono44khz", [1, 0, 0])])
+def test_vq_stage_matches_oracle_on_random_entries(probe, name, pattern, tmp_path):
+    """Random classifications / entry numbers over the fixtures' real codebooks and residue setups (format 2 stereo with
+    partially unused channels, format 1 mono), long and short blocks, 8 streams: device == oracle, bit for bit."""
+    spec, _, _ = load_golden(name)
+    d = _dump(probe, name, tmp_path)
+    pk, seg, vqp, cls, ent, want = _random_vq_batch(spec, d["vq_spec"], 8, 24, pattern, seed=7)
+    syn = Synth(spec, max_streams=8)
+    syn.attach_vq(d["vq_spec"])
+    ys = np.zeros((len(pk), spec.channels, syn.ys_stride), np.uint16)
+    out = syn.submit_host_vq(pk, seg, ys, vqp, cls, ent, want.size, 24 * spec.blocksize1 // 2)
+    assert out["rc"] == 0, out
+    assert np.array_equal(out["residue"].view(np.uint32), want.view(np.uint32))
+
+
+def test_vq_stage_reports_bad_streams(probe, tmp_path):
+    spec, _, _ = load_golden("test.stereo44khz")
+    d = _dump(probe, "test.stereo44khz", tmp_path)
+    pk, seg, vqp, cls, ent, want = _random_vq_batch(spec, d["vq_spec"], 2, 6, [1], seed=3)
+    syn = Synth(spec, max_streams=2)
+    with pytest.raises(VsynError):  # not attached yet
+        syn.submit_host_vq(pk, seg, np.zeros((len(pk), 2, syn.ys_stride), np.uint16), vqp, cls, ent, want.size, 6 * 1024)
+    syn.attach_vq(d["vq_spec"])
+    ys = np.zeros((len(pk), 2, syn.ys_stride), np.uint16)
+    # an entry number beyond its codebook
+    bad = ent.copy()
+    k = int(vqp["entry_off"][7])
+    bad[k] = 65535
+    out = syn.submit_host_vq(pk, seg, ys, vqp, cls, bad, want.size, 6 * 1024)
+    assert out["rc"] == VSYN_ERR_STREAM and out["flags"] & VSYN_ST_BAD_VQ and out["first_bad"] == 7
+    # an entry count that does not match the classifications
+    short = vqp.copy()
+    short["num_entries"][3] -= 1
+    out = syn.submit_host_vq(pk, seg, ys, short, cls, ent, want.size, 6 * 1024)
+    assert out["rc"] == VSYN_ERR_STREAM and out["flags"] & VSYN_ST_BAD_VQ and out["first_bad"] == 3
+    # a clean batch afterwards is clean
+    out = syn.submit_host_vq(pk, seg, ys, vqp, cls, ent, want.size, 6 * 1024)
+    assert out["rc"] == 0 and np.array_equal(out["residue"].view(np.uint32), want.view(np.uint32))
+    # setups outside the stage's limits are refused with a reason
+    books = list(d["vq_spec"].codebooks)
+    res = [dict(r) for r in d["vq_spec"].residues]
+    res[0]["partition_size"] = 7
+    with pytest.raises(VsynError, match="divide"):
+        syn.attach_vq(VqSpec(books, res, d["vq_spec"].mappings))

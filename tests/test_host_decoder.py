@@ -10,7 +10,7 @@ import pytest
 import __graft_entry__ as entry
 from parseoggvorbis_amd.binding import PACKET_DTYPE
 from tests.dump_reader import read_dump
-from tests.workloads import GOLDEN, load_golden
+from tests.workloads import GOLDEN, load_golden, read_entropy_dump
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "parseoggvorbis_amd", "host")
@@ -41,27 +41,63 @@ def has_gpu():
 
 @pytest.mark.parametrize("name", ["test.stereo44khz", "test.mono44khz"])
 def test_entropy_half_matches_reference_hooks(probe, name, tmp_path):
-    """mode / window flags / page granules / 'floor1 ys' / 'after_residue' of every packet == reference (exact)."""
-    if has_gpu():
-        pytest.skip("probe relies on the synthesis batch failing without a GPU")
+    """mode / window flags / page granules / 'floor1 ys' / 'after_residue' of every packet == reference (exact).
+    Float-residue mode of the host decoder (PARSEOGGVORBIS_VQ=0)."""
+    spec, b, _ = load_golden(name)
+    out = str(tmp_path / "e.bin")
+    r = subprocess.run([probe, os.path.join(GOLDEN, name + ".ogg"), out], capture_output=True, text=True,
+                       env=dict(os.environ, PARSEOGGVORBIS_VQ="0"))
+    assert r.returncode == 0, r.stderr
+    d = read_entropy_dump(out)
+    assert (d["P"], d["channels"], d["blocksize0"], d["blocksize1"]) == (len(b["packets"]), spec.channels, spec.blocksize0,
+                                                                         spec.blocksize1)
+    for k in ("mode", "prev_long", "next_long", "floor_used", "granule"):
+        assert np.array_equal(d["packets"][k], b["packets"][k]), k
+    assert np.array_equal(d["ys"], b["ys"])
+    assert np.array_equal(d["residue"].view(np.uint32), b["residue"].view(np.uint32))
+    assert "vq_packets" not in d
+
+
+@pytest.mark.parametrize("name", ["test.stereo44khz", "test.mono44khz"])
+def test_vq_entries_rebuild_reference_residue(probe, name, tmp_path):
+    """VQ mode (default): the host ships classification + entry numbers; the ORACLE's accumulate stage
+    (hpp:725-757 restated) turns them back into the reference decoder's 'after_residue', bit for bit, for every packet
+    of both fixtures (format 2 stereo, format 1 mono). Pins oracle + host entry stream against the reference."""
+    from oracle import oracle_binding as ob
     spec, b, _ = load_golden(name)
     out = str(tmp_path / "e.bin")
     r = subprocess.run([probe, os.path.join(GOLDEN, name + ".ogg"), out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "no HIP device" in r.stdout  # the synthesis half refused to run on the CPU
-    raw = open(out, "rb").read()
-    P, Cn, stride, nres, bs0, bs1 = np.frombuffer(raw[:24], np.uint32)
-    assert (P, Cn, bs0, bs1) == (len(b["packets"]), spec.channels, spec.blocksize0, spec.blocksize1)
-    off = 24
-    pk = np.frombuffer(raw[off:off + 16 * P], PACKET_DTYPE)
-    off += 16 * P
-    ys = np.frombuffer(raw[off:off + 2 * P * Cn * stride], np.uint16).reshape(P, Cn, stride)
-    off += 2 * P * Cn * stride
-    res = np.frombuffer(raw[off:off + 4 * nres], np.float32)
-    for k in ("mode", "prev_long", "next_long", "floor_used", "granule"):
-        assert np.array_equal(pk[k], b["packets"][k]), k
-    assert np.array_equal(ys, b["ys"])
-    assert np.array_equal(res.view(np.uint32), b["residue"].view(np.uint32))
+    d = read_entropy_dump(out)
+    assert d["residue"].size == 0 and d["residue_floats"] == b["residue"].size and len(d["vq_packets"]) == d["P"]
+    assert np.array_equal(d["ys"], b["ys"])
+    Cn = spec.channels
+    off = 0
+    for p in range(d["P"]):
+        mode = int(d["packets"]["mode"][p])
+        n2 = spec.blocksize_of_mode(mode) // 2
+        vp = d["vq_packets"][p]
+        c0 = int(vp["cls_off"])
+        c1 = int(d["vq_packets"][p + 1]["cls_off"]) if p + 1 < d["P"] else d["cls"].size
+        e0, ne = int(vp["entry_off"]), int(vp["num_entries"])
+        # floor_output_used after the nonzero propagate (hpp:1174-1180)
+        used = int(d["packets"]["floor_used"][p])
+        for mag, ang in spec.mappings[spec.modes[mode][1]][0]:
+            if (used >> mag) & 1 or (used >> ang) & 1:
+                used |= (1 << mag) | (1 << ang)
+        rc, res = ob.residue_vq(d["vq_spec"], spec.modes[mode][1], Cn, n2, used, d["cls"][c0:c1], d["entries"][e0:e0 + ne])
+        assert rc == 0, (p, rc)
+        want = b["residue"][off:off + Cn * n2]
+        assert np.array_equal(res.view(np.uint32), want.view(np.uint32)), p
+        off += Cn * n2
+    assert off == b["residue"].size
+    # a damaged entry stream is reported, not mis-decoded
+    vp = d["vq_packets"][5]
+    e0, ne = int(vp["entry_off"]), int(vp["num_entries"])
+    mode = int(d["packets"]["mode"][5])
+    rc, _ = ob.residue_vq(d["vq_spec"], spec.modes[mode][1], Cn, spec.blocksize_of_mode(mode) // 2, 3, d["cls"][int(vp["cls_off"]):],
+                          d["entries"][e0:e0 + ne - 1])
+    assert rc == 64  # VSYN_ST_BAD_VQ
 
 
 def test_cli_contract(built, tmp_path):

@@ -152,3 +152,107 @@ def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, yl
             pk[s * packets_per_stream + packets_per_stream - 1]["granule"] = total - min(37, last_l // 2)  # clipped last packet
     plane = packets_per_stream * (spec.blocksize1 // 2) + 64
     return dict(packets=pk, segments=seg, ys=ys, residue=np.concatenate(res_parts), plane_stride=plane)
+
+
+def read_entropy_dump(path):
+    """Parse the file written by tests/host_entropy_dump.cpp -> dict (packets, ys, residue, and in VQ mode vq_packets,
+    cls, entries, residue_floats, vq_spec)."""
+    from parseoggvorbis_amd.binding import PACKET_DTYPE, VQ_PACKET_DTYPE, VqSpec
+    raw = open(path, "rb").read()
+    P, Cn, stride, nres, bs0, bs1 = (int(x) for x in np.frombuffer(raw[:24], np.uint32))
+    off = 24
+    d = dict(P=P, channels=Cn, ys_stride=stride, blocksize0=bs0, blocksize1=bs1)
+    d["packets"] = np.frombuffer(raw[off:off + 16 * P], PACKET_DTYPE).copy()
+    off += 16 * P
+    d["ys"] = np.frombuffer(raw[off:off + 2 * P * Cn * stride], np.uint16).reshape(P, Cn, stride).copy()
+    off += 2 * P * Cn * stride
+    d["residue"] = np.frombuffer(raw[off:off + 4 * nres], np.float32).copy()
+    off += 4 * nres
+    if off == len(raw):
+        return d
+
+    def u32():
+        nonlocal off
+        v = int(np.frombuffer(raw[off:off + 4], np.uint32)[0])
+        off += 4
+        return v
+
+    assert u32() == 0x31305156
+    nvq, ncls, nent, rfl = u32(), u32(), u32(), u32()
+    d["vq_packets"] = np.frombuffer(raw[off:off + 16 * nvq], VQ_PACKET_DTYPE).copy()
+    off += 16 * nvq
+    d["cls"] = np.frombuffer(raw[off:off + ncls], np.uint8).copy()
+    off += ncls
+    d["entries"] = np.frombuffer(raw[off:off + 2 * nent], np.uint16).copy()
+    off += 2 * nent
+    d["residue_floats"] = rfl
+    books = []
+    for _ in range(u32()):
+        dims, n, has = u32(), u32(), u32()
+        tab = None
+        if has:
+            tab = np.frombuffer(raw[off:off + 4 * dims * n], np.float32).copy()
+            off += 4 * dims * n
+        books.append((dims, n, tab))
+    residues = []
+    for _ in range(u32()):
+        r = dict(type=u32(), begin=u32(), end=u32(), partition_size=u32(), num_classifications=u32(), classwords=u32())
+        nb = r["num_classifications"] * 8
+        r["books"] = np.frombuffer(raw[off:off + 2 * nb], np.int16).copy()
+        off += 2 * nb
+        residues.append(r)
+    maps = []
+    for _ in range(u32()):
+        ns = u32()
+        mux = list(raw[off:off + Cn])
+        off += Cn
+        sres = list(raw[off:off + ns])
+        off += ns
+        maps.append((mux, sres))
+    assert off == len(raw)
+    d["vq_spec"] = VqSpec(books, residues, maps)
+    return d
+
+
+def build_probe(tmpdir):
+    """Compile tests/host_entropy_dump.cpp against the built host library; returns the executable's path."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "parseoggvorbis_amd", "host")
+    csrc = os.path.join(root, "parseoggvorbis_amd", "csrc")
+    out = os.path.join(str(tmpdir), "host_entropy_dump")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-o", out, os.path.join(root, "tests", "host_entropy_dump.cpp"),
+                    "-L" + host, "-lparseoggvorbis_amd", "-L" + csrc, "-lvorbis_synth_hip", "-Wl,-rpath," + host,
+                    "-Wl,-rpath," + csrc, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    return out
+
+
+def synth_vq_packet(vq_spec, mapping, channels, n2, used_mask, rng):
+    """Random but well-formed (cls, entries) of one packet for `mapping`, in the decode order of hpp:708-760."""
+    mux, sres = vq_spec.mappings[mapping]
+    cls_all, ent_all = [], []
+    for s in range(len(sres)):
+        chans = [c for c in range(channels) if mux[c] == s]
+        if not chans:
+            continue
+        r = vq_spec.residues[sres[s]]
+        fmt2 = r["type"] == 2
+        vch = 1 if fmt2 else len(chans)
+        ln = len(chans) * n2 if fmt2 else n2
+        parts = (min(r["end"], ln) - min(r["begin"], ln)) // r["partition_size"]
+        cls = rng.integers(0, r["num_classifications"], (vch, parts)).astype(np.uint8)
+        used = [True] if fmt2 else [bool((used_mask >> c) & 1) for c in chans]
+        for ps in range(8):
+            for pc in range(parts):
+                for j in range(vch):
+                    if not used[j]:
+                        continue
+                    book = int(r["books"][int(cls[j, pc]) * 8 + ps])
+                    if book < 0:
+                        continue
+                    dims, n, _ = vq_spec.codebooks[book]
+                    ent_all.append(rng.integers(0, n, r["partition_size"] // dims).astype(np.uint16))
+        cls_all.append(cls.ravel())
+    cls = np.concatenate(cls_all) if cls_all else np.zeros(0, np.uint8)
+    ent = np.concatenate(ent_all) if ent_all else np.zeros(0, np.uint16)
+    return cls, ent
