@@ -80,11 +80,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config2"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config2", "config3_vq"],
+                    help="config3_vq: config 3 with the residue given as VQ entry numbers (device VQ stage, SURVEY 8 f-1)")
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--packets-per-stream", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--staged", action="store_true", help="time the staged kernels instead of the fused one")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="do not let a submit's pre-kernels overlap the previous submit (diagnostic: standalone kernel times)")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +114,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     # the synthetic descriptors are resident and final before the timed region: consecutive submits may overlap their
     # pre-kernels with the previous synthesis kernel (every kernel of every step still runs inside the timed region)
-    flags = VSYN_SUBMIT_STAGED if args.staged else VSYN_SUBMIT_INPUTS_READY
+    flags = VSYN_SUBMIT_STAGED if args.staged else (0 if args.no_overlap else VSYN_SUBMIT_INPUTS_READY)
 
     if args.workload == "config2":
         n, count = 256, 4096
@@ -124,8 +127,8 @@ def main():
         units, bytes_per_unit, wl = count, 1536, "config2: 4096 mono packets, blocksize 256, IMDCT only"
         b = None
     else:
-        pattern = "long" if args.workload == "config3" else "mixed"
-        ppk = args.packets_per_stream or (1024 if args.workload == "config3" else 512)
+        pattern = "long" if args.workload in ("config3", "config3_vq") else "mixed"
+        ppk = args.packets_per_stream or (1024 if pattern == "long" else 512)
         b = build_batch(spec, args.streams, ppk, pattern, 1234 + rank, device)
         gpu = Synth(spec, device=local, max_streams=args.streams)
         pcm = torch.zeros((b["S"], spec.channels, b["plane"]), device=device)
@@ -133,6 +136,34 @@ def main():
         step = lambda: gpu.submit_device(b["P"], b["packets"].data_ptr(), b["S"], b["segments"].data_ptr(), b["ppk"],
                                          b["ys"].data_ptr(), b["residue"].data_ptr(), pcm.data_ptr(), b["plane"],
                                          emit.data_ptr(), None, flags, stream)
+        vq_entries_per_packet = None
+        if args.workload == "config3_vq":
+            # same batch, but "after_residue" is rebuilt on the device from classification + entry numbers
+            from tests.workloads import synthetic_vq_spec, synth_vq_packet
+            from parseoggvorbis_amd.binding import VQ_PACKET_DTYPE
+            vqs = synthetic_vq_spec(spec.channels, spec.blocksize1)
+            gpu.attach_vq(vqs)
+            rng = np.random.default_rng(77 + rank)
+            pool = [synth_vq_packet(vqs, 1, spec.channels, spec.blocksize1 // 2, 3, rng) for _ in range(256)]
+            pick = rng.integers(0, len(pool), b["P"])
+            cls = np.concatenate([pool[i][0] for i in pick])
+            ent = np.concatenate([pool[i][1] for i in pick])
+            vqp = np.zeros(b["P"], VQ_PACKET_DTYPE)
+            vqp["num_entries"] = [pool[i][1].size for i in pick]
+            vqp["entry_off"] = np.concatenate([[0], np.cumsum(vqp["num_entries"][:-1], dtype=np.uint64)])
+            vqp["cls_off"] = np.concatenate([[0], np.cumsum([pool[i][0].size for i in pick][:-1])])
+            d_vqp = torch.from_numpy(vqp.view(np.uint8)).to(device)
+            d_cls = torch.from_numpy(cls).to(device)
+            d_ent = torch.from_numpy(ent.view(np.int16)).to(device)
+            d_res = [torch.zeros_like(b["residue"]) for _ in range(2)]  # double buffered: submits overlap
+            vq_entries_per_packet = float(ent.size) / b["P"]
+            count = [0]
+
+            def step():
+                count[0] += 1
+                gpu.submit_device_vq(b["P"], b["packets"].data_ptr(), b["S"], b["segments"].data_ptr(), b["ppk"], b["ys"].data_ptr(),
+                                     d_vqp.data_ptr(), d_cls.data_ptr(), cls.size, d_ent.data_ptr(), ent.size,
+                                     d_res[count[0] & 1].data_ptr(), pcm.data_ptr(), b["plane"], emit.data_ptr(), flags, stream)
         units = b["P"]
         posts = {0: len(spec.floors[0][1]), 1: len(spec.floors[1][1])}
         lng_frac = float((b["n_of"] == spec.blocksize1).mean())
@@ -143,6 +174,12 @@ def main():
         wl = ("config3: %d stereo packets, blocksize 2048, %d streams x %d, floor+coupling+IMDCT+window+overlap-add"
               % (b["P"], b["S"], ppk)) if pattern == "long" else \
              ("config4: %d stereo packets, mixed 2048/256 (%.0f%% long), %d streams x %d" % (b["P"], 100 * lng_frac, b["S"], ppk))
+        if vq_entries_per_packet is not None:
+            # the roofline object of this workload describes the residue VQ kernel: entry + classification numbers and
+            # the two 16/32-byte descriptors in, the rebuilt residue out
+            bytes_per_unit = vq_entries_per_packet * 2 + float(cls.size) / b["P"] + 16 + 32 + spec.channels * (spec.blocksize1 // 2) * 4
+            wl = ("config3_vq: config 3 with the residue as VQ entry numbers (%.0f entries/packet, synthetic format-2 setup); "
+                  "residue VQ kernel + synthesis" % vq_entries_per_packet)
 
     def barrier():
         if world > 1:
@@ -154,7 +191,7 @@ def main():
     fl, bad = gpu.sync_status(stream)
     assert fl == 0, "device flagged the synthetic batch: 0x%x at packet %d" % (fl, bad)
 
-    gpu.profile(2 if args.workload == "config4" else 1)
+    gpu.profile({"config4": 2, "config3_vq": 3}.get(args.workload, 1))
     gpu.profile_read()
     barrier()
     torch.cuda.synchronize()
@@ -178,6 +215,17 @@ def main():
         hs = b["host_segments"][:ns].copy()
         hy = b["ys"][:ns * b["ppk"]].cpu().numpy().view(np.uint16)
         hr = b["residue"][:ns * b["per_stream_floats"]].cpu().numpy()
+        if vq_entries_per_packet is not None:
+            # the synthesis consumed the residue the VQ kernel rebuilt: check that against the oracle's VQ stage on a few
+            # packets, then feed the synthesis oracle with it
+            from oracle import oracle_binding as ob
+            hr = d_res[count[0] & 1][:ns * b["per_stream_floats"]].cpu().numpy()
+            per_pk = spec.channels * (spec.blocksize1 // 2)
+            for q in (0, 1, ns * b["ppk"] - 1):
+                e0, ne, c0 = int(vqp["entry_off"][q]), int(vqp["num_entries"][q]), int(vqp["cls_off"][q])
+                c1 = int(vqp["cls_off"][q + 1]) if q + 1 < len(vqp) else cls.size
+                rc_o, want_r = ob.residue_vq(vqs, 1, spec.channels, spec.blocksize1 // 2, 3, cls[c0:c1], ent[e0:e0 + ne])
+                assert rc_o == 0 and np.array_equal(want_r.view(np.uint32), hr[q * per_pk:(q + 1) * per_pk].view(np.uint32)), q
         orc = OracleSynth(spec, ns)
         want = orc.submit_host(hp, hs, hy, hr, b["plane"])
         got = pcm[:ns].cpu().numpy()

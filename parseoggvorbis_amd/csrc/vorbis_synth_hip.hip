@@ -91,7 +91,7 @@ struct vsyn_handle {
   std::vector<uint8_t> host_const;
   uint8_t* d_const = nullptr;
   uint8_t* d_vq = nullptr;             // residue VQ stage: VqHeader, books, residues, maps, value pool (vsyn_attach_vq)
-  uint32_t vq_max_slots = 0;
+  uint32_t vq_lds_bytes = 0;           // dynamic LDS of the residue VQ kernel
   DevBuf<vsyn_vq_packet> st_vqpk;      // vsyn_submit_host_vq staging
   DevBuf<uint8_t> st_cls;
   DevBuf<uint16_t> st_ent;
@@ -126,7 +126,7 @@ struct vsyn_handle {
   DevBuf<uint32_t> st_emit;
   // profiling
   bool profile = false;
-  int profile_which = 1;  // 1: long-run fused kernel, 2: mixed-block fused kernel
+  int profile_which = 1;  // 1: long-run fused kernel, 2: mixed-block fused kernel, 3: residue VQ kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   const char* profile_kernel = "";
@@ -402,7 +402,7 @@ size_t vsyn_const_block_bytes(const vsyn_handle* h) { return h ? h->host_const.s
 int vsyn_profile_enable(vsyn_handle* h, int on) {
   if (!h) return VSYN_ERR_INVALID;
   h->profile = on != 0;
-  if (on == 1 || on == 2) h->profile_which = on;
+  if (on >= 1 && on <= 3) h->profile_which = on;
   return VSYN_OK;
 }
 
@@ -526,10 +526,12 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,
                                                                                                        d_ys, fy, h->d_status);
   }
-  if (d_vq)
-    vsyn_residue_vq_kernel<<<P, VQ_THREADS, (size_t)h->vq_max_slots * sizeof(uint32_t), ps>>>(h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls,
-                                                                                              d_vq->num_cls, d_vq->entries, d_vq->num_entries,
-                                                                                              d_residue, h->d_status);
+  if (d_vq) {
+    if (h->profile_which == 3) HIPCHK(profile_begin(h, ps, "vsyn_residue_vq_kernel"));
+    vsyn_residue_vq_kernel<<<std::min<uint32_t>(P, (uint32_t)h->num_cus * 32u), VQ_THREADS, h->vq_lds_bytes, ps>>>(
+        h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
+  }
+  if (d_vq && h->profile_which == 3) HIPCHK(profile_end(h, ps));
   HIPCHK(hipEventRecord(h->ev_pre_done[wb], ps));
   if (ps != s) HIPCHK(hipStreamWaitEvent(s, h->ev_pre_done[wb], 0));
 
@@ -633,7 +635,10 @@ int vsyn_attach_vq(vsyn_handle* h, const vsyn_vq_setup* vq, const char** err) {
   h->d_vq = nullptr;
   HIPCHK(hipMalloc((void**)&h->d_vq, block.size()));
   HIPCHK(hipMemcpy(h->d_vq, block.data(), block.size(), hipMemcpyHostToDevice));
-  h->vq_max_slots = ((const VqHeader*)block.data())->max_slots;
+  {
+    const VqHeader* vh = (const VqHeader*)block.data();
+    h->vq_lds_bytes = vh->max_slots / 2u * (uint32_t)sizeof(uint32_t) + 16u;
+  }
   return VSYN_OK;
 }
 

@@ -256,3 +256,33 @@ def synth_vq_packet(vq_spec, mapping, channels, n2, used_mask, rng):
     cls = np.concatenate(cls_all) if cls_all else np.zeros(0, np.uint8)
     ent = np.concatenate(ent_all) if ent_all else np.zeros(0, np.uint16)
     return cls, ent
+
+
+def synthetic_vq_spec(channels=2, bs1=2048, seed=5):
+    """A residue VQ setup in the shape of the stereo fixture's long-block residue (format 2, begin 0, end 1600 of 2048
+    interleaved bins, partition 32, 10 classes, three cascade passes, vector lengths 8/4/2/1), with small-integer value
+    tables. Mapping 0 (short blocks) and 1 (long blocks) share it. For benchmarks and tests that need codebooks without an
+    .ogg file."""
+    from parseoggvorbis_amd.binding import VqSpec
+    rng = np.random.default_rng(seed)
+    books = []
+    for dims, n, amp in ((8, 256, 1), (4, 256, 2), (4, 81, 1), (2, 128, 3), (2, 64, 1), (1, 32, 8), (1, 16, 2)):
+        tab = rng.integers(-amp, amp + 1, (n, dims)).astype(np.float32)
+        tab[rng.random((n, dims)) < 0.5] = 0
+        books.append((dims, n, tab.ravel()))
+    nclass = 10
+    cas = np.full((nclass, 8), -1, np.int16)
+    cas[1, 0] = 0
+    cas[2, 0], cas[2, 1] = 1, 4
+    cas[3, 0] = 2
+    cas[4, 0], cas[4, 1] = 3, 6
+    cas[5, 1] = 4
+    cas[6, 0], cas[6, 1], cas[6, 2] = 1, 3, 5
+    cas[7, 2] = 6
+    cas[8, 0], cas[8, 2] = 0, 5
+    cas[9, 0], cas[9, 1], cas[9, 2] = 2, 4, 6
+    n2 = bs1 // 2
+    end = (channels * n2 * 25 // 32) // 32 * 32  # 1600 of 2048 for stereo 2048
+    res = dict(type=2, begin=0, end=end, partition_size=32, num_classifications=nclass, classwords=2, books=cas.ravel())
+    mux = [0] * channels
+    return VqSpec(books, [res], [(mux, [0]), (mux, [0])])

@@ -1,5 +1,6 @@
 # tools/profile_round.sh <tag> — rocprofv3 passes over `bench.py` on the GPU box, raw output under gpurun_out/<tag>/,
 # summaries (what gets committed under profiles/) written by tools/pmc_summarize.py.  Run from the repo root.
+# BENCH_ARGS (environment) is appended to the bench command, e.g. "--workload config3_vq".
 # Kernel timing and every PMC group are separate runs (gpurun refuses --pmc combined with tracing).
 set -e
 TAG=${1:-prof}
@@ -7,7 +8,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_ARGS"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $BENCH > $OUT/stats.log 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
