@@ -249,6 +249,20 @@ int vsyn_submit_host_vq(vsyn_handle* h,
                         uint32_t* emit_len, const vsyn_taps* taps,
                         uint32_t flags, vsyn_status* status, const char** err);
 
+/* ---- PCM post-stage: planar f32 -> what the consumer of gotPcmData does next ----
+ * Converts the PCM of the MOST RECENT vsyn_submit_device* call on this handle (stream-ordered: pass the same hip_stream)
+ * from planar [S][channels][plane_stride] to interleaved frames [S][out_stride_frames][channels]; segment g gets its
+ * total emitted frames (the sum of its emit_len), also written to d_frames[g] if d_frames != NULL.
+ *   VSYN_PCM_S16  int16, host endian, val = round-to-nearest-even(x * 32768.f) clamped to [-32768, 32767] — ov_read's
+ *                 conversion (reference tree: tests/libvorbis-standalone/vorbis_vorbisfile.c:2026-2029 with vorbis_ftoi of
+ *                 os.h:156-158); halves the output bytes
+ *   VSYN_PCM_F32  float32, values unchanged */
+#define VSYN_PCM_S16 1
+#define VSYN_PCM_F32 2
+int vsyn_pcm_interleave_device(vsyn_handle* h, int format, const float* d_pcm, uint64_t plane_stride,
+                               void* d_out, uint64_t out_stride_frames, uint32_t* d_frames,
+                               void* hip_stream, const char** err);
+
 /* Page-locked host memory for the buffers handed to vsyn_submit_host (direct DMA instead of the runtime's staging copies;
  * what a host decoder that batches at corpus scale wants). Pageable memory is accepted by vsyn_submit_host as well. */
 int vsyn_host_alloc(size_t bytes, void** out, const char** err);

@@ -68,6 +68,8 @@ def oracle():
         lib.orc_reset_streams.argtypes = [vp]
         lib.orc_reset_streams.restype = None
         lib.orc_submit.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, u64, vp, C.POINTER(Taps), C.POINTER(Status)]
+        lib.orc_pcm_interleave.argtypes = [C.c_int, u32, u32, vp, u64, vp]
+        lib.orc_pcm_interleave.restype = None
         lib.orc_residue_vq.argtypes = [C.POINTER(VqSetup), u32, u32, u32, u32, vp, C.c_size_t, vp, C.c_size_t, vp]
         _orc = lib
     return _orc
@@ -168,3 +170,13 @@ def residue_vq(vq_spec, mapping, channels, n2, used_mask, cls, entries):
     rc = lib.orc_residue_vq(C.byref(su), mapping, channels, n2, used_mask, cls.ctypes.data if cls.size else None, cls.size,
                             entries.ctypes.data if entries.size else None, entries.size, out.ctypes.data)
     return rc, out
+
+
+def pcm_interleave(fmt, planar, frames):
+    """Oracle of the PCM post-stage: planar float32 [C][stride] -> interleaved [frames][C] (int16 for fmt 1, float32 for 2)."""
+    lib = oracle()
+    planar = np.ascontiguousarray(planar, np.float32)
+    Cn, stride = planar.shape
+    out = np.zeros((frames, Cn), np.int16 if fmt == 1 else np.float32)
+    lib.orc_pcm_interleave(fmt, Cn, frames, planar.ctypes.data, stride, out.ctypes.data)
+    return out

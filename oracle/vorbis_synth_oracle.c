@@ -777,3 +777,23 @@ int orc_residue_vq(const vsyn_vq_setup* vq, uint32_t mapping, uint32_t channels,
   if (ent != ent_end) return VSYN_ST_BAD_VQ; /* the packet's entry count must match what its classifications call for */
   return 0;
 }
+
+
+/* PCM post-stage: vorbis_vorbisfile.c:2022-2032 (host-endian signed 16-bit branch) / float pass-through */
+#include <fenv.h>
+void orc_pcm_interleave(int format, uint32_t channels, uint32_t frames, const float* planar, uint64_t plane_stride, void* out) {
+  for (uint32_t i = 0; i < channels; ++i) {
+    const float* src = planar + (size_t)i * plane_stride;
+    for (uint32_t j = 0; j < frames; ++j) {
+      if (format == VSYN_PCM_S16) {
+        volatile float prod = src[j] * 32768.f;   /* the product is rounded to f32 first (vorbis_ftoi takes a double of it) */
+        long val = lrint((double)prod);           /* cvtsd2si: current rounding mode = to nearest even */
+        if (val > 32767) val = 32767;
+        else if (val < -32768) val = -32768;
+        ((int16_t*)out)[(size_t)j * channels + i] = (int16_t)val;
+      } else {
+        ((float*)out)[(size_t)j * channels + i] = src[j];
+      }
+    }
+  }
+}

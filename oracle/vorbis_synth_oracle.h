@@ -66,6 +66,12 @@ int orc_submit(orc_handle* h,
 int orc_residue_vq(const vsyn_vq_setup* vq, uint32_t mapping, uint32_t channels, uint32_t n2, uint32_t used_mask,
                    const uint8_t* cls, size_t num_cls, const uint16_t* entries, size_t num_entries, float* out);
 
+/* ---- PCM post-stage: planar f32 -> interleaved int16 / f32 ----
+ * PARITY UNPINNED by execution: the rule is ov_read's (reference tree tests/libvorbis-standalone/vorbis_vorbisfile.c:2026-2029,
+ * vorbis_ftoi of os.h:156-158: cvtsd2si of the f32 product x * 32768.f, round to nearest even; clamp to [-32768, 32767]), restated
+ * from the text; that file cannot be compiled here (ogg/config_types.h is not vendored) and no fixture holds s16 output. */
+void orc_pcm_interleave(int format, uint32_t channels, uint32_t frames, const float* planar, uint64_t plane_stride, void* out);
+
 /* IMDCT only, for BASELINE config 2 and the cpu_baseline leg */
 void orc_imdct_batch(int n, uint32_t count, const float* in, float* out);
 

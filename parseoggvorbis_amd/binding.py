@@ -19,6 +19,7 @@ VSYN_ST_BAD_SEGMENT, VSYN_ST_BAD_VQ = 32, 64
 VSYN_SEG_RESET = 1
 VSYN_SUBMIT_STAGED = 1
 VSYN_SUBMIT_INPUTS_READY = 2
+VSYN_PCM_S16, VSYN_PCM_F32 = 1, 2
 
 
 class Floor1(C.Structure):
@@ -171,7 +172,7 @@ _SYMBOLS = [
     "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels",
     "vsyn_const_block_bytes", "vsyn_submit_device", "vsyn_submit_host", "vsyn_sync_status", "vsyn_reset_streams",
     "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device", "vsyn_host_alloc", "vsyn_host_free",
-    "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq",
+    "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq", "vsyn_pcm_interleave_device",
 ]
 
 
@@ -222,6 +223,7 @@ def load():
                                           C.POINTER(Taps), u32, vp, cpp]
     lib.vsyn_submit_host_vq.argtypes = [vp, u32, vp, u32, vp, vp, C.POINTER(VqBatch), vp, C.c_size_t, vp, u64, vp,
                                         C.POINTER(Taps), u32, C.POINTER(Status), cpp]
+    lib.vsyn_pcm_interleave_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, vp, vp, cpp]
     lib.vsyn_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp), cpp]
     lib.vsyn_host_free.argtypes = [vp]
     lib.vsyn_host_free.restype = None
@@ -341,6 +343,14 @@ class Synth:
         tp = C.byref(Taps(*taps)) if taps else None
         rc = self.lib.vsyn_submit_device(self.h, P, d_packets, S, d_segments, max_seg_packets, d_ys, d_residue,
                                          d_pcm, plane_stride, d_emit, tp, flags, stream, C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
+
+    def pcm_interleave_device(self, fmt, d_pcm, plane_stride, d_out, out_stride_frames, d_frames=None, stream=None):
+        """Interleave / convert the PCM of the most recent submit_device* (raw device addresses)."""
+        err = C.c_char_p()
+        rc = self.lib.vsyn_pcm_interleave_device(self.h, fmt, d_pcm, plane_stride, d_out, out_stride_frames, d_frames, stream,
+                                                 C.byref(err))
         if rc != VSYN_OK:
             raise VsynError(rc, (err.value or b"").decode())
 

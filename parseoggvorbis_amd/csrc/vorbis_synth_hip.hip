@@ -22,6 +22,7 @@
 #include "vsyn_staged.h"
 #include "vsyn_fused.h"
 #include "vsyn_vq.h"
+#include "vsyn_pcm.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846264338327
@@ -92,6 +93,7 @@ struct vsyn_handle {
   uint8_t* d_const = nullptr;
   uint8_t* d_vq = nullptr;             // residue VQ stage: VqHeader, books, residues, maps, value pool (vsyn_attach_vq)
   uint32_t vq_lds_bytes = 0;           // dynamic LDS of the residue VQ kernel
+  uint32_t last_S = 0, last_wb = 0;    // segments / workspace half of the most recent submit (vsyn_pcm_interleave_device)
   DevBuf<vsyn_vq_packet> st_vqpk;      // vsyn_submit_host_vq staging
   DevBuf<uint8_t> st_cls;
   DevBuf<uint16_t> st_ent;
@@ -602,6 +604,8 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   }
   HIPCHK(hipEventRecord(h->ev_main_done[wb], s));
   h->main_done_valid[wb] = true;
+  h->last_S = S;
+  h->last_wb = wb;
   HIPCHK(hipGetLastError());
   return VSYN_OK;
 }
@@ -758,6 +762,26 @@ int vsyn_submit_host_vq(vsyn_handle* h, uint32_t P, const vsyn_packet* packets, 
   if (!vq && P && S) return fail(err, VSYN_ERR_INVALID, "vq batch is NULL");
   return submit_host_impl(h, P, packets, S, segments, ys, nullptr, vq, residue_out, residue_floats, pcm, plane_stride, emit_len, taps, flags, status,
                           err);
+}
+
+int vsyn_pcm_interleave_device(vsyn_handle* h, int format, const float* d_pcm, uint64_t plane_stride, void* d_out, uint64_t out_stride_frames,
+                               uint32_t* d_frames, void* hip_stream, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  if (format != VSYN_PCM_S16 && format != VSYN_PCM_F32) return fail(err, VSYN_ERR_INVALID, "unknown PCM format %d", format);
+  if (!d_pcm || !d_out || plane_stride == 0 || out_stride_frames == 0) return fail(err, VSYN_ERR_INVALID, "NULL pointer / zero stride");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->last_S == 0) return fail(err, VSYN_ERR_INVALID, "no submit on this handle yet");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const uint64_t cap = std::min<uint64_t>(std::min(plane_stride, out_stride_frames), 0xFFFFFFFFull);
+  const dim3 grid((uint32_t)((cap + 1023) / 1024), h->last_S);
+  const SegInfo* si = h->ws_seg[h->last_wb].p;
+  if (format == VSYN_PCM_S16)
+    vsyn_pcm_interleave_kernel<VSYN_PCM_S16><<<grid, 256, 0, s>>>(h->d_const, si, h->last_S, d_pcm, plane_stride, d_out, out_stride_frames, d_frames);
+  else
+    vsyn_pcm_interleave_kernel<VSYN_PCM_F32><<<grid, 256, 0, s>>>(h->d_const, si, h->last_S, d_pcm, plane_stride, d_out, out_stride_frames, d_frames);
+  HIPCHK(hipGetLastError());
+  return VSYN_OK;
 }
 
 int vsyn_host_alloc(size_t bytes, void** out, const char** err) {
