@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--pcm-s16", action="store_true",
+                    help="config3/config4: append the PCM post-stage (planar f32 -> interleaved int16, SURVEY 8 f-3) to every step")
     ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config2", "config3_vq"],
                     help="config3_vq: config 3 with the residue given as VQ entry numbers (device VQ stage, SURVEY 8 f-1)")
     ap.add_argument("--streams", type=int, default=64)
@@ -164,6 +166,15 @@ def main():
                 gpu.submit_device_vq(b["P"], b["packets"].data_ptr(), b["S"], b["segments"].data_ptr(), b["ppk"], b["ys"].data_ptr(),
                                      d_vqp.data_ptr(), d_cls.data_ptr(), cls.size, d_ent.data_ptr(), ent.size,
                                      d_res[count[0] & 1].data_ptr(), pcm.data_ptr(), b["plane"], emit.data_ptr(), flags, stream)
+        pcm_stage_ms = None
+        if args.pcm_s16:
+            from parseoggvorbis_amd.binding import VSYN_PCM_S16
+            d_s16 = torch.zeros((b["S"], b["plane"], spec.channels), dtype=torch.int16, device=device)
+            inner = step
+
+            def step():
+                inner()
+                gpu.pcm_interleave_device(VSYN_PCM_S16, pcm.data_ptr(), b["plane"], d_s16.data_ptr(), b["plane"], None, stream)
         units = b["P"]
         posts = {0: len(spec.floors[0][1]), 1: len(spec.floors[1][1])}
         lng_frac = float((b["n_of"] == spec.blocksize1).mean())
@@ -258,6 +269,21 @@ def main():
         cpu = {"value": round(4096 * reps / t_cpu, 1), "unit": "packets/s", "cores": 1, "kind": "port",
                "sample": "the same 4096 blocks, %d repetitions, %.1f s" % (reps, t_cpu)}
 
+    pcm_stage = None
+    if b is not None and args.pcm_s16 and rank == 0:
+        # the post-stage on its own: same buffers, torch events on the launch stream
+        from parseoggvorbis_amd.binding import VSYN_PCM_S16
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            gpu.pcm_interleave_device(VSYN_PCM_S16, pcm.data_ptr(), b["plane"], d_s16.data_ptr(), b["plane"], None, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        frames = int(emit.sum().item())
+        nbytes = frames * spec.channels * (4 + 2)
+        pcm_stage = {"kernel": "vsyn_pcm_interleave_kernel", "kernel_ms": round(ms, 5), "algorithmic_bytes": nbytes,
+                     "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if rank == 0:
         value = total_units * args.steps / dt
         achieved = bytes_per_unit * units / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
@@ -271,7 +297,7 @@ def main():
                          "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kern_name, "kernel_ms": round(kern_ms, 5), "launches": launches,
                          "algorithmic_bytes_per_packet": round(bytes_per_unit, 1)},
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "pcm_stage_s16": pcm_stage,
             "pcm_max_abs_err_vs_oracle": max_err, "pcm_peak": None if max_err is None else pcm_peak,
         }
         print(json.dumps(line))
