@@ -587,19 +587,11 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     a.fused_ok = h->fused_mask;
     a.coupling_mode = (uint32_t)h->fused.coupling_mode;
     if (staged_may_work) HIPCHK(hipEventRecord(h->ev_join, h->side));
-    if (h->profile_which == 1) HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
+    // one launch covers the long-run and the mixed-block runs (each wave takes the path of its run's class)
+    if (h->profile_which == 1 || h->profile_which == 2) HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
     hipError_t e = fused_launch(H, h->fused, a, max_seg_packets, s);
     if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
-    if (h->profile_which == 1) HIPCHK(profile_end(h, s));
-    if (h->fused_mask & 2u) {
-      // mixed-block runs: after the long-run kernel on the same stream, NOT beside it — the long kernel's grid is sized to
-      // fill the chip in exactly one round, and even idle co-scheduled workgroups push part of it into a second one
-      // (measured +20 %). Its workgroups leave at once when the batch has no such run.
-      if (h->profile_which == 2) HIPCHK(profile_begin(h, s, "vsyn_fused_mixed_kernel"));
-      e = fused_mixed_launch(H, h->fused, a, max_seg_packets, s);
-      if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused mixed launch failed: %s", hipGetErrorString(e));
-      if (h->profile_which == 2) HIPCHK(profile_end(h, s));
-    }
+    if (h->profile_which == 1 || h->profile_which == 2) HIPCHK(profile_end(h, s));
     if (staged_may_work) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   }
   HIPCHK(hipEventRecord(h->ev_main_done[wb], s));

@@ -469,41 +469,6 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   }
 }
 
-// grid: x = groups of FUSED_WAVES (run, channel) units — the channels of a run sit in adjacent waves of one workgroup so
-// that the partner-channel loads of a coupled pair hit L1/L2 instead of HBM —, y = segment
-__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_long_kernel(const FusedArgs A) {
-  __shared__ FusedLdsImage s_t;
-  __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
-  __shared__ float4 s_seg[FUSED_WAVES][64];
-  __shared__ uint32_t s_flag[FUSED_WAVES][2];
-  const ConstHeader* H = hdr_of(A.cb);
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t g = blockIdx.y, C = H->channels;
-  if (g >= A.S) return;
-  const vsyn_segment sg = A.segs[g];
-  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // whole workgroup: the layout kernel flagged the segment
-  const uint32_t unit = blockIdx.x * FUSED_WAVES + wave;
-  const uint32_t run = unit / C, c = unit % C;
-  const uint32_t qa = run * A.R;
-  const uint32_t qb = min(sg.num_packets, qa + A.R);
-  const SegInfo si = A.sinfo[g];
-  const bool active = run < A.runs_per_seg && A.run_cls[(size_t)g * A.runs_per_seg + run] == 1;
-  if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing in this workgroup for this kernel: leave before staging the tables
-  {
-    const uint4* src = (const uint4*)A.lds_image;
-    uint4* dst = (uint4*)&s_t;
-    for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
-    if (threadIdx.x < FUSED_WAVES * 2) (&s_flag[0][0])[threadIdx.x] = 0u;
-  }
-  __syncthreads();  // the only workgroup-wide barrier: from here on a wave meets nobody but its coupling partner (pair_post/pair_wait)
-  if (!active) return;  // a run is active for all its channels or for none: no partner is left waiting
-  const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
-  if (A.coupling_mode == 0 || C < 2) fused_run<0>(A, s_t, s_x[wave], s_x[wave], s_seg[wave], (lds_u32*)s_flag[wave], (const lds_u32*)s_flag[wave], lane, g, sg, si, qa, qb, C, c, c);
-  else if (c == mag) fused_run<1>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], (lds_u32*)s_flag[wave], (const lds_u32*)s_flag[wave ^ 1u], lane, g, sg, si, qa, qb, C, c, ang);
-  else fused_run<2>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], (lds_u32*)s_flag[wave], (const lds_u32*)s_flag[wave ^ 1u], lane, g, sg, si, qa, qb, C, c, mag);
-}
-
 // ================================================================================================
 // Mixed-block runs (short and long blocks, window switches, carry-in from an earlier submit).
 // Same decomposition — one wavefront per (run, channel), channel pairs sharing their input through LDS — but the
@@ -569,7 +534,8 @@ __device__ __forceinline__ float floor_at(const float4* __restrict__ seg, const 
 
 template <int ROLE>
 __device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb,
-                                                float4* __restrict__ seg, const uint32_t lane, const uint32_t g, const vsyn_segment sg,
+                                                float4* __restrict__ seg, lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane,
+                                                const uint32_t g, const vsyn_segment sg,
                                                 const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c,
                                                 const uint32_t pc) {
   const uint8_t* __restrict__ cb = A.cb;
@@ -590,21 +556,16 @@ __device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedL
   }
   uint32_t prev_half = (qa == 0) ? (si.has_carry ? si.carry_n / 2u : 0u) : 0u;  // samples the previous block put into this chunk
 
-  for (uint32_t it = 0; it <= A.R; ++it) {
+  // (pairwise hand-off with the partner channel's wave as in fused_run: my_flags[0] "my image holds packet #n's residue",
+  // my_flags[1] "I have read yours"; both waves of a pair walk the same packets and skip the same ones)
+  for (uint32_t it = 0; q0 + it < qb; ++it) {
     const uint32_t q = q0 + it;
-    if (q >= qb) {
-      lds_barrier();
-      lds_barrier();
-      continue;
-    }
     const uint32_t p = sg.first_packet + q;
     const PktInfo pi = A.info[p];
     const bool halo = q < qa, last_of_segment = q + 1 == num;
     const PktInfo pin = A.info[last_of_segment ? p : p + 1];
     if (spk_mode_invalid(H, A.packets[p].mode)) {
       // invalid mode number: the layout kernel flagged it; nothing to synthesise (outputs after it are unspecified)
-      lds_barrier();
-      lds_barrier();
       prev_half = 0;
       continue;
     }
@@ -627,17 +588,16 @@ __device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedL
 #pragma unroll
       for (int t = 0; t < 8; ++t)
         if (t == 0 || lng) xb[t * 64 + lane] = r[t];
-    }
-    lds_barrier();
-    if (ROLE != 0) {
+      pair_post(&my_flags[0], it + 1);
+      pair_wait(&partner_flags[0], it + 1);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
         if (t == 0 || lng) {
           const float2 oth = pxb[t * 64 + lane];
           r[t] = ROLE == 1 ? f2(couple_mag(r[t].x, oth.x), couple_mag(r[t].y, oth.y)) : f2(couple_ang(oth.x, r[t].x), couple_ang(oth.y, r[t].y));
         }
+      pair_post(&my_flags[1], it + 1);
     }
-    lds_barrier();
 
     // ---- floor curve + product ---------------------------------------------------------------------------------
     uint32_t sidx_unused, floor_id;
@@ -669,6 +629,7 @@ __device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedL
     float* const nxt = last_of_segment ? carry_out : plane + pin.out_pos;
     const uint32_t nlimit = last_of_segment ? M : ((q + 1 >= qa) ? pin.emit : 0u);
 
+    if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT / the next packet may reuse it
     if (lng) {
       // ---- IMDCT (as in fused_run) ----
       float2 z[8];
@@ -727,10 +688,16 @@ __device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedL
 }
 
 static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a workgroup");
-__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_mixed_kernel(const FusedArgs A) {
+// ONE launch for both kinds of run. grid: x = groups of FUSED_WAVES (run, channel) units — the channels of a run sit in
+// adjacent waves of one workgroup, which is what the pairwise LDS hand-off needs —, y = segment. Every wave looks up the
+// class the layout kernel gave its run (1: all long blocks, steady windows, no carry-in -> fused_run; 2: anything else the
+// fused paths cover -> fused_mixed_run) and takes that path; waves of one workgroup may take different ones (they only ever
+// meet their coupling partner, which shares the run and therefore the class).
+__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_kernel(const FusedArgs A) {
   __shared__ FusedLdsImage s_t;
   __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
   __shared__ float4 s_seg[FUSED_WAVES][64];
+  __shared__ uint32_t s_flag[FUSED_WAVES][2];
   const ConstHeader* H = hdr_of(A.cb);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
@@ -743,25 +710,32 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   const uint32_t qa = run * A.R;
   const uint32_t qb = min(sg.num_packets, qa + A.R);
   const SegInfo si = A.sinfo[g];
-  const bool active = run < A.runs_per_seg && A.run_cls[(size_t)g * A.runs_per_seg + run] == 2;
-  if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing in this workgroup for this kernel: leave before staging the tables
+  uint32_t cls = run < A.runs_per_seg ? (uint32_t)A.run_cls[(size_t)g * A.runs_per_seg + run] : 0xFFu;
+  cls = __builtin_amdgcn_readfirstlane(cls);
+  const bool active = (cls == 1u && (A.fused_ok & 1u)) || (cls == 2u && (A.fused_ok & 2u));
+  if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing in this workgroup: leave before staging the tables
   {
     const uint4* src = (const uint4*)A.lds_image;
     uint4* dst = (uint4*)&s_t;
     for (uint32_t i = threadIdx.x; i < sizeof(FusedLdsImage) / 16; i += FUSED_WAVES * 64) dst[i] = src[i];
+    if (threadIdx.x < FUSED_WAVES * 2) (&s_flag[0][0])[threadIdx.x] = 0u;
   }
-  __syncthreads();  // from here on waves only meet at the pair-sharing barriers inside the run loop
-  if (!active) {  // keep the workgroup's barrier count balanced
-    for (uint32_t it = 0; it <= A.R; ++it) {
-      lds_barrier();
-      lds_barrier();
-    }
-    return;
-  }
+  __syncthreads();  // the only workgroup-wide barrier: from here on a wave meets nobody but its coupling partner (pair_post/pair_wait)
+  if (!active) return;  // a run is active for all its channels or for none: no partner is left waiting
   const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
-  if (A.coupling_mode == 0 || C < 2) fused_mixed_run<0>(A, s_t, s_x[wave], s_x[wave], s_seg[wave], lane, g, sg, si, qa, qb, C, c, c);
-  else if (c == mag) fused_mixed_run<1>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, ang);
-  else fused_mixed_run<2>(A, s_t, s_x[wave], s_x[wave ^ 1u], s_seg[wave], lane, g, sg, si, qa, qb, C, c, mag);
+  const int role = (A.coupling_mode == 0 || C < 2) ? 0 : (c == mag ? 1 : 2);
+  const uint32_t pw = role ? (wave ^ 1u) : wave;  // partner wave
+  lds_u32* mf = (lds_u32*)s_flag[wave];
+  const lds_u32* pf = (const lds_u32*)s_flag[pw];
+  if (cls == 1u) {
+    if (role == 0) fused_run<0>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, c);
+    else if (role == 1) fused_run<1>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
+    else fused_run<2>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
+  } else {
+    if (role == 0) fused_mixed_run<0>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, c);
+    else if (role == 1) fused_mixed_run<1>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
+    else fused_mixed_run<2>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,7 +856,7 @@ static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t
   }
   ft->coupling_mode = fused_coupling_mode(H, host_const);
   int blocks = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vsyn_fused_long_kernel, FUSED_WAVES * 64, 0) == hipSuccess && blocks > 0)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vsyn_fused_kernel, FUSED_WAVES * 64, 0) == hipSuccess && blocks > 0)
     ft->waves_per_cu = blocks * FUSED_WAVES;
   return hipSuccess;
 }
@@ -894,7 +868,7 @@ static inline void fused_tables_destroy(FusedTables* ft) {
   ft->d_lds = nullptr;
 }
 
-static inline const char* fused_kernel_name(const ConstHeader&) { return "vsyn_fused_long_kernel"; }
+static inline const char* fused_kernel_name(const ConstHeader&) { return "vsyn_fused_kernel"; }
 static inline const char* fused_imdct_kernel_name(uint32_t) { return "vsyn_imdct_plain_kernel"; }
 
 // run length: as few runs as fill the chip once (halo overhead is 1/R), never below 4
@@ -913,18 +887,11 @@ static inline hipError_t fused_launch(const ConstHeader& H, const FusedTables& f
   const char* xl = getenv("VSYN_EXTRA_LDS");  // experiment knob: extra dynamic LDS lowers the occupancy
   const size_t dyn = xl ? (size_t)atoi(xl) : 0;
   a.coupling_mode = (uint32_t)ft.coupling_mode;
-  vsyn_fused_long_kernel<<<grid, FUSED_WAVES * 64, dyn, s>>>(a);
+  vsyn_fused_kernel<<<grid, FUSED_WAVES * 64, dyn, s>>>(a);
   return hipGetLastError();
 }
 
 // runs with short blocks / window switches / a carry-in: same grid, every wave of a run the long kernel took idles out
-static inline hipError_t fused_mixed_launch(const ConstHeader& H, const FusedTables& ft, FusedArgs a, uint32_t max_seg_packets, hipStream_t s) {
-  const uint32_t units = ((max_seg_packets + a.R - 1) / a.R) * H.channels;
-  dim3 grid((units + FUSED_WAVES - 1) / FUSED_WAVES, a.S);
-  a.coupling_mode = (uint32_t)ft.coupling_mode;
-  vsyn_fused_mixed_kernel<<<grid, FUSED_WAVES * 64, 0, s>>>(a);
-  return hipGetLastError();
-}
 
 static inline hipError_t fused_imdct_launch(const ConstHeader&, const uint8_t*, const FusedTables&, int, uint32_t, uint32_t,
                                             const float*, float*, hipStream_t, bool* done) {

@@ -29,7 +29,7 @@ for path in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"
     for (name, ctr), d in per.items():
         vals = sorted(d.values())
         out["kernels"].setdefault(name, {}).setdefault("pmc_mean_per_launch", {})[ctr] = sum(vals) / len(vals)
-lk = out["kernels"].get("vsyn_fused_long_kernel", {}).get("pmc_mean_per_launch", {})
+lk = out["kernels"].get("vsyn_fused_kernel", {}).get("pmc_mean_per_launch", {})
 if "FETCH_SIZE" in lk and "WRITE_SIZE" in lk:
     # KiB units; FETCH_SIZE counts half of the streamed bytes on gfx950 (MI355X_MICROARCH.md HBM section; tools/fetch_calib.hip)
     out["long_kernel_hbm_bytes_per_launch"] = {"read_corrected": lk["FETCH_SIZE"] * 1024 * 2, "write": lk["WRITE_SIZE"] * 1024}
