@@ -121,6 +121,10 @@ typedef struct vsyn_taps {            /* optional debug taps = the reference's p
   float* after_envelope;              /* same packing as residue; "after_envelope", hpp:1254 */
   float* pcm_after_mdct;              /* packed like residue with n_p per channel (2x offsets); "pcm_after_mdct", hpp:1265 */
   uint16_t* floor_final;              /* [P][channels][ys_stride]: final_y*multiplier | step2_flag<<15 ("floor1 final_ys"/"step2_flag", hpp:560-561) */
+  uint16_t* floor_curve;              /* packed like residue (n_p/2 per channel): the rendered integer floor curve, "floor1 floor"
+                                         (hpp:585; the reference's vector has n_p entries: the second half is flat at the last flagged post's y, hpp:583-584);
+                                         with after_residue these are the feature tensors of returnn_import.py:74-115.
+                                         Rows of channels without a decoded floor are left untouched */
 } vsyn_taps;
 
 typedef struct vsyn_status {

@@ -143,9 +143,10 @@ class OracleSynth:
         if want_taps:
             taps = dict(after_envelope=np.zeros(residue.size, np.float32),
                         pcm_after_mdct=np.zeros(residue.size * 2, np.float32),
-                        floor_final=np.zeros(ys.size, np.uint16))
+                        floor_final=np.zeros(ys.size, np.uint16),
+                        floor_curve=np.zeros(residue.size, np.uint16))
             tp = Taps(taps["after_envelope"].ctypes.data, taps["pcm_after_mdct"].ctypes.data,
-                      taps["floor_final"].ctypes.data)
+                      taps["floor_final"].ctypes.data, taps["floor_curve"].ctypes.data)
         st = Status()
         rc = self.lib.orc_submit(self.h, P, p(packets), S, p(segments), p(ys), p(residue), p(pcm), plane_stride,
                                  p(emit), C.byref(tp) if tp else None, C.byref(st))

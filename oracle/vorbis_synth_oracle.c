@@ -614,10 +614,15 @@ int orc_submit(orc_handle* h, uint32_t num_packets, const vsyn_packet* packets, 
         const uint32_t f = h->maps[mode->mapping].chfloor[c];
         uint32_t y32[VSYN_MAX_POSTS], fy[VSYN_MAX_POSTS];
         uint8_t fl[VSYN_MAX_POSTS];
+        uint32_t curve[VSYN_MAX_BLOCKSIZE];
         const uint16_t* row = ys + ((size_t)p * C + c) * h->ys_stride;
         for (uint32_t i = 0; i < h->floors[f].posts; ++i) y32[i] = row[i];
         int rc = orc_floor1_synth(h->floors[f].xs, (int)h->floors[f].posts, (int)h->floors[f].mult, y32, n,
-                                  h->floor_buf + (size_t)n * c, fy, fl, NULL);
+                                  h->floor_buf + (size_t)n * c, fy, fl, curve);
+        if (taps && taps->floor_curve && rc != VSYN_ST_FLOOR_RANGE) { /* "floor1 floor", hpp:585 (first n/2 of the n rendered values) */
+          uint16_t* t = taps->floor_curve + res_off + (size_t)c * n2;
+          for (uint32_t i = 0; i < n2; ++i) t[i] = (uint16_t)(curve[i] > 65535u ? 65535u : curve[i]);
+        }
         if (rc) { flag_status(status, (uint32_t)rc, p); bad = 1; break; }
         used |= 1u << c;
         if (taps && taps->floor_final) {

@@ -47,7 +47,8 @@ class Setup(C.Structure):
 
 
 class Taps(C.Structure):
-    _fields_ = [("after_envelope", C.c_void_p), ("pcm_after_mdct", C.c_void_p), ("floor_final", C.c_void_p)]
+    _fields_ = [("after_envelope", C.c_void_p), ("pcm_after_mdct", C.c_void_p), ("floor_final", C.c_void_p),
+                ("floor_curve", C.c_void_p)]
 
 
 class Status(C.Structure):
@@ -283,9 +284,10 @@ class Synth:
         if want_taps:
             taps = dict(after_envelope=np.zeros(residue.size, np.float32),
                         pcm_after_mdct=np.zeros(residue.size * 2, np.float32),
-                        floor_final=np.zeros(ys.size, np.uint16))
+                        floor_final=np.zeros(ys.size, np.uint16),
+                        floor_curve=np.zeros(residue.size, np.uint16))
             tp = Taps(taps["after_envelope"].ctypes.data, taps["pcm_after_mdct"].ctypes.data,
-                      taps["floor_final"].ctypes.data)
+                      taps["floor_final"].ctypes.data, taps["floor_curve"].ctypes.data)
         st, err = Status(), C.c_char_p()
         rc = self.lib.vsyn_submit_host(self.h, P, _ptr(packets), S, _ptr(segments), _ptr(ys), _ptr(residue),
                                        residue.size, _ptr(pcm), plane_stride, _ptr(emit),

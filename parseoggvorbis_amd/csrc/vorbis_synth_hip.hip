@@ -125,6 +125,7 @@ struct vsyn_handle {
   DevBuf<vsyn_segment> st_seg;
   DevBuf<uint16_t> st_ys, st_fy;
   DevBuf<float> st_res, st_pcm, st_env, st_blk;
+  DevBuf<uint16_t> st_curve;
   DevBuf<uint32_t> st_emit;
   // profiling
   bool profile = false;
@@ -379,7 +380,7 @@ void vsyn_destroy(vsyn_handle* h) {
   }
   if (h->d_const) (void)hipFree(h->d_const);
   if (h->d_vq) (void)hipFree(h->d_vq);
-  h->st_vqpk.release(); h->st_cls.release(); h->st_ent.release();
+  h->st_curve.release(); h->st_vqpk.release(); h->st_cls.release(); h->st_ent.release();
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_carry) (void)hipFree(h->d_carry);
   if (h->d_status) (void)hipFree(h->d_status);
@@ -490,7 +491,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   hipStream_t s = (hipStream_t)hip_stream;
   const ConstHeader& H = h->H;
   const uint32_t C = H.channels;
-  const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct);
+  const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct || taps->floor_curve);
   const bool force_staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !h->fused_ok;
   const uint32_t R = force_staged ? std::min<uint32_t>(max_seg_packets, 1024u)
                                   : fused_pick_run_len(h->fused, S, C, max_seg_packets, h->num_cus);
@@ -559,7 +560,8 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
       blk = h->ws_blk.p;
     }
     const uint32_t grid = force_staged ? std::min<uint32_t>(P * C, 256u * 32u) : 512u;
-    vsyn_spectrum_kernel<<<std::min<uint32_t>(grid, P), 256, 0, ss>>>(h->d_const, list, cnt, info, d_residue, fy, env, h->d_status);
+    vsyn_spectrum_kernel<<<std::min<uint32_t>(grid, P), 256, 0, ss>>>(h->d_const, list, cnt, info, d_residue, fy, env,
+                                                                      taps ? taps->floor_curve : nullptr, h->d_status);
     if (force_staged) HIPCHK(profile_begin(h, s, "vsyn_imdct_staged_kernel"));
     vsyn_imdct_staged_kernel<<<grid, 256, (size_t)H.bs[1] * 4, ss>>>(h->d_const, list, cnt, info, env, blk);
     if (force_staged) HIPCHK(profile_end(h, s));
@@ -682,7 +684,7 @@ static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packe
   HIPCHK(h->st_res.ensure(residue_floats + 4));
   HIPCHK(h->st_pcm.ensure(pcm_n));
   HIPCHK(h->st_emit.ensure(P));
-  vsyn_taps dt = {nullptr, nullptr, nullptr};
+  vsyn_taps dt = {nullptr, nullptr, nullptr, nullptr};
   if (taps && taps->after_envelope) {
     HIPCHK(h->st_env.ensure(residue_floats + 4));
     dt.after_envelope = h->st_env.p;
@@ -694,6 +696,10 @@ static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packe
   if (taps && taps->floor_final) {
     HIPCHK(h->st_fy.ensure(ys_n));
     dt.floor_final = h->st_fy.p;
+  }
+  if (taps && taps->floor_curve) {
+    HIPCHK(h->st_curve.ensure(residue_floats + 4));
+    dt.floor_curve = h->st_curve.p;
   }
   // Everything runs on the handle's own stream, so that several handles driven from several host threads overlap their
   // copies and kernels (the NULL stream would serialise them). With pinned host buffers (vsyn_host_alloc) the copies are
@@ -720,9 +726,10 @@ static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packe
   }
   HIPCHK(hipMemsetAsync(h->st_pcm.p, 0, sizeof(float) * pcm_n, hs));
   if (dt.floor_final) HIPCHK(hipMemsetAsync(h->st_fy.p, 0, ys_n * sizeof(uint16_t), hs));
+  if (dt.floor_curve) HIPCHK(hipMemsetAsync(dt.floor_curve, 0, sizeof(uint16_t) * residue_floats, hs));
   if (dt.after_envelope) HIPCHK(hipMemsetAsync(dt.after_envelope, 0, sizeof(float) * residue_floats, hs));
   if (dt.pcm_after_mdct) HIPCHK(hipMemsetAsync(dt.pcm_after_mdct, 0, sizeof(float) * 2 * residue_floats, hs));
-  const bool any_tap = dt.after_envelope || dt.pcm_after_mdct || dt.floor_final;
+  const bool any_tap = dt.after_envelope || dt.pcm_after_mdct || dt.floor_final || dt.floor_curve;
   int rc = submit_device_impl(h, P, h->st_pk.p, S, h->st_seg.p, max_seg, h->st_ys.p, vq ? &dvq : nullptr, h->st_res.p, h->st_pcm.p, plane_stride,
                               h->st_emit.p, any_tap ? &dt : nullptr, flags & ~VSYN_SUBMIT_INPUTS_READY, hs, err);
   if (rc) return rc;
@@ -733,6 +740,7 @@ static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packe
   if (dt.after_envelope) HIPCHK(hipMemcpyAsync(taps->after_envelope, dt.after_envelope, sizeof(float) * residue_floats, hipMemcpyDeviceToHost, hs));
   if (dt.pcm_after_mdct) HIPCHK(hipMemcpyAsync(taps->pcm_after_mdct, dt.pcm_after_mdct, sizeof(float) * 2 * residue_floats, hipMemcpyDeviceToHost, hs));
   if (dt.floor_final) HIPCHK(hipMemcpyAsync(taps->floor_final, dt.floor_final, sizeof(uint16_t) * ys_n, hipMemcpyDeviceToHost, hs));
+  if (dt.floor_curve) HIPCHK(hipMemcpyAsync(taps->floor_curve, dt.floor_curve, sizeof(uint16_t) * residue_floats, hipMemcpyDeviceToHost, hs));
   vsyn_status st;
   rc = vsyn_sync_status(h, hs, &st, err);
   if (status) *status = st;

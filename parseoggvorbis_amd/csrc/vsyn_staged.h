@@ -406,7 +406,7 @@ __device__ __forceinline__ void inverse_couple(float& m, float& a) {  // hpp:122
 __global__ void __launch_bounds__(256)
 vsyn_spectrum_kernel(const uint8_t* __restrict__ cb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                      const PktInfo* __restrict__ info, const float* __restrict__ residue, const uint16_t* __restrict__ fy,
-                     float* __restrict__ env, DevStatus* __restrict__ status) {
+                     float* __restrict__ env, uint16_t* __restrict__ curve_tap, DevStatus* __restrict__ status) {
   const ConstHeader* H = hdr_of(cb);
   const uint32_t total = *count;
   for (uint32_t li = blockIdx.x; li < total; li += gridDim.x) {  // grid-stride over the staged work list
@@ -433,6 +433,7 @@ vsyn_spectrum_kernel(const uint8_t* __restrict__ cb, const uint32_t* __restrict_
     if ((pi.own >> c) & 1u) {
       const FloorConst* fc = floor_of(cb, mc->chfloor[c]);
       const uint32_t v = floor1_curve_at(fc, fy + ((size_t)p * C + c) * H->ys_stride, i);
+      if (curve_tap) curve_tap[pi.res_off + (size_t)c * n2 + i] = (uint16_t)min(v, 65535u);  // "floor1 floor", hpp:585
       if (v >= 256u) {  // hpp:587
         raise_status(status, VSYN_ST_FLOOR_VALUE, p);
         f = 0.f;

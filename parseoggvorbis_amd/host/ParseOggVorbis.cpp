@@ -867,8 +867,8 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
   std::vector<uint32_t> emit(P, 0);
   const bool hooks = decoder_wants_data(this);
   std::vector<float> env, blk;
-  std::vector<uint16_t> ffin;
-  vsyn_taps taps = {nullptr, nullptr, nullptr};
+  std::vector<uint16_t> ffin, fcurve;
+  vsyn_taps taps = {nullptr, nullptr, nullptr, nullptr};
   if (vq_mode_ && hooks) residue_.assign(residue_floats_, 0.f);  // the "after_residue" hook needs the floats back from the device
   if (hooks) {
     env.resize(residue_floats_);
@@ -877,6 +877,8 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
     taps.after_envelope = env.data();
     taps.pcm_after_mdct = blk.data();
     taps.floor_final = ffin.data();
+    fcurve.resize(residue_floats_);
+    taps.floor_curve = fcurve.data();
   }
   vsyn_segment seg;
   memset(&seg, 0, sizeof(seg));
@@ -932,8 +934,19 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
           push_data_u32(this, "floor1 ys", -1, y32.data(), posts);
           push_data_u32(this, "floor1 final_ys", -1, fy.data(), posts);
           push_data_bool(this, "floor1 step2_flag", -1, flag);
-          // "floor1 floor" / "floor_outputs" (the rendered curve) never leave the GPU registers; compare-debug-out.py
-          // lists both as ignorable (tests/compare-debug-out.py:192-195)
+          // "floor1 floor" (hpp:585): n values upstream; the device tap holds the first n/2. The rest is flat (hpp:583-584
+          // extends the last flagged post's y to the end of the vector): the y of the post at x = n/2 (header index 1) if it
+          // is flagged, else the extension began earlier and bin n/2-1 already carries it
+          {
+            std::vector<uint32_t> curve(n);
+            const uint16_t* crow = &fcurve[roff + (size_t)ch * n2];
+            for (uint32_t i = 0; i < n2; ++i) curve[i] = crow[i];
+            const uint32_t tail = (frow[1] >> 15) ? (uint32_t)(frow[1] & 0x7fffu) : (uint32_t)crow[n2 - 1];
+            for (uint32_t i = n2; i < n; ++i) curve[i] = tail;
+            push_data_u32(this, "floor1 floor", -1, curve.data(), n);
+          }
+          // "floor_outputs" (its inverse-dB image, float) is not emitted; compare-debug-out.py lists it as ignorable
+          // (tests/compare-debug-out.py:192-195)
         }
       }
       for (uint32_t ch = 0; ch < C; ++ch) push_data_float(this, "after_residue", (int)ch, &residue_[roff + (size_t)ch * n2], n2);

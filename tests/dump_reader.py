@@ -70,7 +70,7 @@ def split_packets(entries, channels):
             continue
         if name == "start_audio_packet":
             assert cur is None or cur.get("finished")
-            cur = {"floor_number": {}, "ys": {}, "final_ys": {}, "flag": {}, "after_residue": {}, "after_envelope": {},
+            cur = {"floor_number": {}, "ys": {}, "final_ys": {}, "flag": {}, "floor": {}, "after_residue": {}, "after_envelope": {},
                    "pcm_after_mdct": {}, "last_ch": -1}
             packets.append(cur)
             continue
@@ -92,7 +92,9 @@ def split_packets(entries, channels):
             cur[name][ch] = v
         elif name in ("abs_total_pos", "expected_ending_total_pos"):
             cur[name] = int(v[0])
+        elif name == "floor1 floor":
+            cur["floor"][cur["last_ch"]] = v
         else:
-            assert name in ("floor1 floor", "floor_outputs", "floor1 fit_value unwrapped"), name
+            assert name in ("floor_outputs", "floor1 fit_value unwrapped"), name
     pcm = [np.concatenate(c) if c else np.zeros(0, np.float32) for c in pcm]
     return setup, packets, pcm

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_pod_layouts_match_header():
     assert binding.PACKET_DTYPE.itemsize == 16 and binding.PACKET_DTYPE.fields["granule"][1] == 8
     assert binding.SEGMENT_DTYPE.itemsize == 24 and binding.SEGMENT_DTYPE.fields["residue_off"][1] == 16
-    assert C.sizeof(binding.Status) == 8 and C.sizeof(binding.Taps) == 24
+    assert C.sizeof(binding.Status) == 8 and C.sizeof(binding.Taps) == 32 and binding.VQ_PACKET_DTYPE.itemsize == 16
 
 
 def test_no_cpu_fallback_without_gpu(lib):

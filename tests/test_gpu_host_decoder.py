@@ -63,6 +63,7 @@ def test_cli_dump_matches_reference(name, batch, tmp_path):
                 if used:
                     assert np.array_equal(p["final_ys"][c], z[key + "final_ys"])
                     assert np.array_equal(p["flag"][c], z[key + "flag"])
+                    assert np.array_equal(p["floor"][c], z[key + "floor"])  # "floor1 floor": all n rendered values
             assert len(p["pcm_after_mdct"][c]) == n
     for c in range(Cn):
         assert len(pcm[c]) == total

@@ -67,6 +67,10 @@ def test_reference_fixture_taps(name):
                 row = r["taps"]["floor_final"].reshape(-1, C, gpu.ys_stride)[k, c, :len(xs)]
                 assert np.array_equal(row & 0x7FFF, z[key + "final_ys"] * mult)
                 assert np.array_equal(row >> 15, z[key + "flag"])
+                cv = r["taps"]["floor_curve"][off[k] + c * n // 2: off[k] + (c + 1) * n // 2]
+                assert np.array_equal(cv, z[key + "floor"][:n // 2]), key  # "floor1 floor" (SURVEY 8 f-4 feature tap)
+                tail = int(row[1] & 0x7FFF) if row[1] >> 15 else int(cv[-1])  # flat from the last flagged post on (hpp:583-584)
+                assert (z[key + "floor"][n // 2:] == tail).all()
 
 
 SHAPES = [  # (channels, bs0, bs1, pattern, streams, packets)
