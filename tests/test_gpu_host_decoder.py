@@ -145,3 +145,58 @@ def test_corpus_decoder_matches_reference_pcm(files_per_submit, feeders):
     for i, n in enumerate(order):
         if i != 5:
             assert np.array_equal(pcm[i], pcm[first[n]])
+
+
+def test_corpus_survives_damaged_files(tmp_path):
+    """Damaged but partly parsable files (bit flips / overwritten bytes with the page CRCs re-computed, truncation) through the
+    whole pipeline, GPU included: good files still decode to the reference PCM, bad ones fail alone, nothing hangs or faults."""
+    import json
+    import subprocess
+    from tests.test_host_decoder import CORPUS_CLI  # noqa: F401
+    rng = np.random.default_rng(77)
+    tab = []
+    for i in range(256):
+        r = i << 24
+        for _ in range(8):
+            r = ((r << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if r & 0x80000000 else (r << 1) & 0xFFFFFFFF
+        tab.append(r)
+
+    def fix_crcs(b):
+        o = 0
+        while o + 27 <= len(b) and b[o:o + 4] == b"OggS":
+            ns = b[o + 26]
+            if o + 27 + ns > len(b):
+                break
+            ln = 27 + ns + sum(b[o + 27:o + 27 + ns])
+            if o + ln > len(b):
+                break
+            b[o + 22:o + 26] = b"\0\0\0\0"
+            c = 0
+            for x in b[o:o + ln]:
+                c = ((c << 8) & 0xFFFFFFFF) ^ tab[((c >> 24) & 0xFF) ^ x]
+            b[o + 22:o + 26] = c.to_bytes(4, "little")
+            o += ln
+
+    names = ["test.stereo44khz", "test.mono44khz"]
+    base = [open(os.path.join(GOLDEN, n + ".ogg"), "rb").read() for n in names]
+    paths = [os.path.join(GOLDEN, names[0] + ".ogg")]  # file 0 is intact
+    for k in range(40):
+        b = bytearray(base[k % 2])
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(4500, len(b)))  # past the headers: audio packets
+            if rng.random() < 0.7:
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            else:
+                b[pos] = int(rng.integers(0, 256))
+        if k % 5 == 0 and len(b) > 9000:
+            del b[int(rng.integers(6000, len(b))):]
+        fix_crcs(b)
+        p = tmp_path / ("d%02d.ogg" % k)
+        p.write_bytes(bytes(b))
+        paths.append(str(p))
+    r = subprocess.run(["timeout", "-k", "10", "120", CORPUS_CLI, "--threads", "4", "--feeders", "2", "--files_per_submit", "8"] + paths,
+                       capture_output=True, text=True)
+    assert r.returncode in (0, 1), (r.returncode, r.stderr[-800:])
+    out = json.loads(r.stdout)
+    assert out["files"] == 41
+    assert out["first_file"]["frames"] == load_golden(names[0])[1]["pcm"].shape[1]  # the intact file is unaffected by its neighbours
