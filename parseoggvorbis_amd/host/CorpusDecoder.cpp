@@ -73,11 +73,12 @@ struct CollectSink : SynthSink {
 
 struct NullCallbacks : ParseCallbacks {};
 
-void entropy_decode_file(const CorpusItem& item, FileRecord& rec) {
+void entropy_decode_file(const CorpusItem& item, FileRecord& rec, SetupCache* cache) {
   NullCallbacks cb;
   CollectSink sink(rec);
   OggReader reader(cb);
   reader.sink_ = &sink;
+  reader.setup_cache_ = cache;
   reader.batch_limit_override_ = 0xffffffffu;  // the whole file is one batch; it is cut into runs on the GPU
   rec.status = reader.full_read_from_memory(item.data, item.len);
   if (rec.status.is_error_)  // keep what was decoded before the failure, as the reference's gotPcmData calls would have
@@ -330,7 +331,7 @@ struct Feeder {
         for (uint32_t c = 0; c < C; ++c) {
           const float* x = &g.pcm[((size_t)s * C + c) * plane];
           chans[c] = DataRange<const float>(x, frames);
-          acc += abs_sum_f32(x, frames);
+          if (opts.checksum) acc += abs_sum_f32(x, frames);
         }
         out.frames = frames;
         out.abs_sum = acc;
@@ -422,6 +423,7 @@ OkOrError decode_corpus(const std::vector<CorpusItem>& items, const CorpusOption
   CorpusStats stats;
   const double t_start = now_s();
 
+  SetupCache setup_cache;
   RecordQueue queue(opts.max_pending_files, (size_t)opts.threads);
   std::atomic<size_t> next(0);
   std::atomic<bool> stop(false);
@@ -436,7 +438,7 @@ OkOrError decode_corpus(const std::vector<CorpusItem>& items, const CorpusOption
         std::unique_ptr<FileRecord> rec = queue.fresh();
         rec->index = i;
         const double t0 = now_s();
-        entropy_decode_file(items[i], *rec);
+        entropy_decode_file(items[i], *rec, opts.share_setups ? &setup_cache : nullptr);
         worker_cpu[(size_t)t] += now_s() - t0;
         if (!queue.push(std::move(rec))) break;
       }
@@ -481,6 +483,8 @@ OkOrError decode_corpus(const std::vector<CorpusItem>& items, const CorpusOption
     stats.handles += l.handles;
   }
 
+  stats.setup_parses = setup_cache.misses;
+  stats.setup_reuses = setup_cache.hits;
   stats.wall_s = now_s() - t_start;
   for (double c : worker_cpu) stats.entropy_cpu_s += c;
   if (stats_out) *stats_out = stats;

@@ -55,6 +55,8 @@ struct CorpusOptions {
   uint32_t max_pending_files = 0;   // entropy-decoded files waiting for the GPU; 0 = 4 * files_per_submit
   int device = 0;                   // HIP ordinal
   bool entropy_only = false;        // diagnostic: run the workers only and count packets (no GPU call, no PCM, frames stay 0)
+  bool share_setups = true;         // parse byte-identical setup headers once per run (SetupCache)
+  bool checksum = true;             // fill CorpusFileResult::abs_sum (one pass over the PCM on the feeder thread)
 };
 
 struct CorpusStats {
@@ -65,6 +67,7 @@ struct CorpusStats {
   double deliver_s = 0;       // feeders: checksums + gotFilePcm
   uint64_t submits = 0, files = 0, audio_packets = 0, frames = 0;
   uint32_t handles = 0;       // distinct synthesis setups seen
+  uint64_t setup_parses = 0, setup_reuses = 0;
 };
 
 // Decodes every item; results[i] belongs to items[i].  The returned status is an error only if the run itself could not

@@ -20,6 +20,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -163,6 +164,24 @@ struct PacketBatch {
   bool first = true;                   // first batch of its stream (no overlap carry-in)
 };
 
+// Parsed setup headers, shared between streams (optional; the corpus decoder installs one per run). Files produced by
+// the same encoder settings carry byte-identical setup packets (38 codebooks for the fixtures: building their decode
+// trees and VQ tables costs more than entropy-decoding two seconds of audio), so a stream whose setup packet is already
+// known copies the parsed model instead of parsing again. Keyed by a hash of the packet bytes, confirmed by comparing
+// the bytes and the id-header fields the parse depends on. Thread safe.
+struct SetupCache {
+  struct Entry {
+    std::vector<uint8_t> bytes;
+    uint32_t channels, blocksizes;
+    std::shared_ptr<const VorbisStreamSetup> setup;
+  };
+  std::mutex mu;
+  std::multimap<uint64_t, Entry> entries;
+  uint64_t hits = 0, misses = 0;
+  std::shared_ptr<const VorbisStreamSetup> find(uint64_t hash, const uint8_t* data, uint32_t len, const VorbisIdHeader& h);
+  void insert(uint64_t hash, const uint8_t* data, uint32_t len, const VorbisIdHeader& h, const VorbisStreamSetup& parsed);
+};
+
 struct VorbisStream;
 // Where finished batches go. Default (nullptr): the stream's own GPU handle, synchronously, followed by the hook /
 // gotPcmData replay. The corpus decoder installs a collector instead and submits many files' batches in one GPU call.
@@ -189,6 +208,8 @@ struct VorbisStream {
   OkOrError parse_setup(const uint8_t* data, uint32_t len, ParseCallbacks& cb);
   OkOrError parse_audio(const uint8_t* data, uint32_t len, int64_t page_granule_or_minus1, ParseCallbacks& cb);
   OkOrError flush(ParseCallbacks& cb);  // run the pending batch on the GPU and replay hooks + gotPcmData in packet order
+
+  SetupCache* setup_cache_ = nullptr;  // optional, see SetupCache
 
   // --- batch state ---
   SynthSink* sink_ = nullptr;
@@ -217,6 +238,7 @@ struct OggReader {
   ParseCallbacks& callbacks_;
 
   SynthSink* sink_ = nullptr;           // optional: where streams hand their batches (see SynthSink)
+  SetupCache* setup_cache_ = nullptr;   // optional: parsed setup headers shared between readers (see SetupCache)
   uint32_t batch_limit_override_ = 0;   // optional: audio packets per batch (0: default / PARSEOGGVORBIS_BATCH)
 
   explicit OggReader(ParseCallbacks& callbacks) : packet_counts_(0), callbacks_(callbacks) {}

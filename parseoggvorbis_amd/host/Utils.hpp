@@ -90,6 +90,7 @@ struct ConstDataReader : IReader {  // borrowed memory, valid for the duration o
 
 // Vorbis bit packing: bit 0 of a byte comes first. Reading past the end yields zero bits and latches reachedEnd()
 // (the reference treats that as "not an error", src/Utils.hpp:338).
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "BitReader's fast path reads the stream as little-endian 64-bit words");
 struct BitReader {
   const uint8_t* p_;
   size_t len_, byte_;
@@ -111,6 +112,15 @@ struct BitReader {
   }
   template <typename T>
   T readBits(int num) {
+    if (num <= 32 && byte_ + 8 <= len_) {  // fast path, as peek + skip
+      uint64_t w;
+      memcpy(&w, p_ + byte_, 8);
+      const uint64_t v = (w >> bit_) & ((1ull << num) - 1ull);
+      const size_t pos = (size_t)bit_ + (size_t)num;
+      byte_ += pos >> 3;
+      bit_ = (int)(pos & 7);
+      return (T)v;
+    }
     uint64_t out = 0;
     int got = 0;
     while (got < num) {
@@ -136,6 +146,11 @@ struct BitReader {
   }
   // next `n` (<= 24) bits without consuming them, zero-padded past the end
   inline uint32_t peek(int n) const {
+    if (byte_ + 8 <= len_) {  // fast path: one unaligned 64-bit little-endian load covers bit_ + n <= 31 bits
+      uint64_t w;
+      memcpy(&w, p_ + byte_, 8);
+      return (uint32_t)((w >> bit_) & ((1ull << n) - 1ull));
+    }
     uint64_t acc = 0;
     int have = 0;
     size_t b = byte_;
@@ -149,6 +164,12 @@ struct BitReader {
     return (uint32_t)(acc & ((1ull << n) - 1ull));
   }
   inline void skip(int n) {
+    if (byte_ + 8 <= len_) {
+      const size_t q = (size_t)bit_ + (size_t)n;
+      byte_ += q >> 3;
+      bit_ = (int)(q & 7);
+      return;
+    }
     size_t pos = byte_ * 8 + (size_t)bit_ + (size_t)n;
     if (pos > len_ * 8) {
       reached_end_ = true;
