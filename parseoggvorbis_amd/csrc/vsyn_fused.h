@@ -379,7 +379,13 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       z[t] = cmulf(f2(r[t].x, im), T.pre[t][lane]);
     }
     if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT may reuse it
+#ifdef VSYN_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(VSYN_EXP_SETPRIO);
+#endif
     fft512_wave(z, xb, &T, lane);
+#ifdef VSYN_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post[k][lane]);
 
