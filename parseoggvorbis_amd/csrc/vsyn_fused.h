@@ -217,7 +217,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   uint32_t prev_next_long = 1;
 
   // lane constants of the floor in use (reloaded only when the floor changes, wave-uniform)
-  uint32_t bseg[4] = {0, 0, 0, 0};  // sorted-post interval of each of this lane's 16 bins, one byte each
+  const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg;  // this wave's entry table inside LDS (entries are 8 bytes)
+  uint32_t bseg[8];  // LDS address of the segment entry of each of this lane's 16 bins, 16 bits each; until a floor is seen:
+                     // entry 0, which is where a channel without a curve finds its constant entry
+#pragma unroll
+  for (int t = 0; t < 8; ++t) bseg[t] = seg_base | (seg_base << 16);
   uint32_t sidx = 0, xsl = 0;       // header index / x of sorted post `lane`
   int cur_floor = -1;
   uint32_t vrow = 0;
@@ -308,8 +312,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         const uint8_t* bs = A.binseg + (size_t)f * M;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));
-          if (t & 1) bseg[t >> 1] |= two << 16; else bseg[t >> 1] = two;
+          const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));  // intervals of bins 2k, 2k+1 (k = lane + 64 t)
+          bseg[t] = (seg_base + 8u * (two & 0xFFu)) | ((seg_base + 8u * (two >> 8)) << 16);
         }
         const bool in = lane < posts;
         sidx = in ? fc->sorted_idx[lane] : 0u;
@@ -359,7 +363,10 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int b = 4 * grp + i;
-        sgm[i] = seg2[(bseg[b >> 2] >> (8 * (b & 3))) & 0xFFu];
+        const uint32_t addr = (b & 1) ? (bseg[b >> 1] >> 16) : (bseg[b >> 1] & 0xFFFFu);  // one VALU op per bin
+        typedef float lds_vf2 __attribute__((ext_vector_type(2)));
+        const lds_vf2 ev = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)addr;
+        sgm[i] = f2(ev.x, ev.y);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -700,10 +707,20 @@ static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a
 // fused paths cover -> fused_mixed_run) and takes that path; waves of one workgroup may take different ones (they only ever
 // meet their coupling partner, which shares the run and therefore the class).
 __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_kernel(const FusedArgs A) {
-  __shared__ FusedLdsImage s_t;
-  __shared__ float2 s_x[FUSED_WAVES][FUSED_XSLOTS];
-  __shared__ float4 s_seg[FUSED_WAVES][64];
-  __shared__ uint32_t s_flag[FUSED_WAVES][2];
+  // one LDS block with a fixed member order: the floor entry tables come first so that their addresses fit the 16 bits
+  // fused_run packs them into (the whole block is 72 KB)
+  struct Lds {
+    float4 seg[FUSED_WAVES][64];
+    uint32_t flag[FUSED_WAVES][2];
+    FusedLdsImage t;
+    float2 x[FUSED_WAVES][FUSED_XSLOTS];
+  };
+  __shared__ Lds s_lds;
+  FusedLdsImage& s_t = s_lds.t;
+  float2 (&s_x)[FUSED_WAVES][FUSED_XSLOTS] = s_lds.x;
+  float4 (&s_seg)[FUSED_WAVES][64] = s_lds.seg;
+  uint32_t (&s_flag)[FUSED_WAVES][2] = s_lds.flag;
+  static_assert(sizeof(s_lds.seg) + sizeof(s_lds.flag) < 65536, "floor entry addresses are packed into 16 bits");
   const ConstHeader* H = hdr_of(A.cb);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
