@@ -9,6 +9,10 @@
 
 #include <algorithm>
 
+static const uint32_t k_inverse_db_bits[256] = {
+#include "../csrc/vorbis_floor1_inverse_db.inc"
+};
+
 // ------------------------------------------------------------------------------------------------
 // utilities
 // ------------------------------------------------------------------------------------------------
@@ -995,9 +999,14 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
             const uint32_t tail = (frow[1] >> 15) ? (uint32_t)(frow[1] & 0x7fffu) : (uint32_t)crow[n2 - 1];
             for (uint32_t i = n2; i < n; ++i) curve[i] = tail;
             push_data_u32(this, "floor1 floor", -1, curve.data(), n);
+            // "floor_outputs" (hpp:1171): the curve through the inverse-dB table (Vorbis I 10.1, hpp:588)
+            std::vector<float> fo(n);
+            for (uint32_t i = 0; i < n; ++i) {
+              const uint32_t bits = k_inverse_db_bits[curve[i] < 256u ? curve[i] : 255u];
+              memcpy(&fo[i], &bits, 4);
+            }
+            push_data_float(this, "floor_outputs", (int)ch, fo.data(), n);
           }
-          // "floor_outputs" (its inverse-dB image, float) is not emitted; compare-debug-out.py lists it as ignorable
-          // (tests/compare-debug-out.py:192-195)
         }
       }
       for (uint32_t ch = 0; ch < C; ++ch) push_data_float(this, "after_residue", (int)ch, &residue_[roff + (size_t)ch * n2], n2);

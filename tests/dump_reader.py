@@ -94,7 +94,10 @@ def split_packets(entries, channels):
             cur[name] = int(v[0])
         elif name == "floor1 floor":
             cur["floor"][cur["last_ch"]] = v
+        elif name == "floor_outputs":
+            assert tid == 1
+            cur.setdefault("floor_outputs", {})[ch] = v
         else:
-            assert name in ("floor_outputs", "floor1 fit_value unwrapped"), name
+            assert name in ("floor1 fit_value unwrapped",), name
     pcm = [np.concatenate(c) if c else np.zeros(0, np.float32) for c in pcm]
     return setup, packets, pcm

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "parseoggvorbis_amd", "host")
 CLI = os.path.join(HOST, "ours_hip.bin")
 TOL = 1e-5
+INVDB = np.ctypeslib.as_array(__import__("oracle.oracle_binding", fromlist=["x"]).oracle().orc_inverse_db_table(), (256,)).copy()
 
 
 @pytest.mark.parametrize("batch", ["2048", "7"])
@@ -64,6 +65,8 @@ def test_cli_dump_matches_reference(name, batch, tmp_path):
                     assert np.array_equal(p["final_ys"][c], z[key + "final_ys"])
                     assert np.array_equal(p["flag"][c], z[key + "flag"])
                     assert np.array_equal(p["floor"][c], z[key + "floor"])  # "floor1 floor": all n rendered values
+                    want_fo = INVDB[z[key + "floor"].astype(np.int64)]             # "floor_outputs" = its inverse-dB image
+                    assert np.array_equal(p["floor_outputs"][c].view(np.uint32), want_fo.view(np.uint32))
             assert len(p["pcm_after_mdct"][c]) == n
     for c in range(Cn):
         assert len(pcm[c]) == total
