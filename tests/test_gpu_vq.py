@@ -128,6 +128,24 @@ def test_vq_stage_matches_oracle_on_random_entries(probe, name, pattern, tmp_pat
     assert np.array_equal(out["residue"].view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("variant", ["format0", "format1x2", "submaps"])
+def test_vq_stage_other_residue_formats(variant):
+    """Residue formats / shapes the fixtures do not have (format 0, two format-1 vectors in one submap with unused channels,
+    vector lengths that are not powers of two, partitions that are not multiples of 8, begin > 0, two submaps): device ==
+    oracle bit for bit on random well-formed entry streams, long and short blocks."""
+    from tests.workloads import exotic_vq_spec, fixture_like_spec
+    spec = fixture_like_spec(2)
+    vqs = exotic_vq_spec(variant)
+    pk, seg, vqp, cls, ent, want = _random_vq_batch(spec, vqs, 6, 20, [1, 0, 1, 1, 0], seed=21)
+    syn = Synth(spec, max_streams=6)
+    syn.attach_vq(vqs)
+    ys = np.zeros((len(pk), 2, syn.ys_stride), np.uint16)
+    out = syn.submit_host_vq(pk, seg, ys, vqp, cls, ent, want.size, 20 * spec.blocksize1 // 2)
+    assert out["rc"] == 0, out
+    assert np.array_equal(out["residue"].view(np.uint32), want.view(np.uint32))
+    assert np.abs(want).max() > 0  # the streams do carry values
+
+
 def test_vq_stage_reports_bad_streams(probe, tmp_path):
     spec, _, _ = load_golden("test.stereo44khz")
     d = _dump(probe, "test.stereo44khz", tmp_path)

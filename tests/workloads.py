@@ -286,3 +286,44 @@ def synthetic_vq_spec(channels=2, bs1=2048, seed=5):
     res = dict(type=2, begin=0, end=end, partition_size=32, num_classifications=nclass, classwords=2, books=cas.ravel())
     mux = [0] * channels
     return VqSpec(books, [res], [(mux, [0]), (mux, [0])])
+
+
+def exotic_vq_spec(variant, channels=2, bs0=256, bs1=2048, seed=9):
+    """Residue setups the fixtures do not have, for oracle-vs-device tests of the VQ stage:
+    'format0'   one submap, residue format 0 (interleaved components, hpp:738-746), partition 16, vector lengths 2/4/8/16
+    'format1x2' one submap holding both channels as two format-1 vectors (partition counter shared, hpp:726-757), partition 12,
+                vector lengths 1/2/3/4/6 (not powers of two, partition not a multiple of 8: the general path and its tails),
+                begin > 0 and end below the block
+    'submaps'   channel 0 -> submap 0 (format 1), channel 1 -> submap 1 (format 0): two residues per packet"""
+    from parseoggvorbis_amd.binding import VqSpec
+    rng = np.random.default_rng(seed)
+
+    def book(dims, n, amp):
+        tab = rng.integers(-amp, amp + 1, (n, dims)).astype(np.float32)
+        return (dims, n, tab.ravel())
+
+    def cascade(nclass, nbooks, density):
+        c = np.full((nclass, 8), -1, np.int16)
+        for k in range(1, nclass):
+            for ps in range(8):
+                if rng.random() < density:
+                    c[k, ps] = int(rng.integers(0, nbooks))
+        return c.ravel()
+
+    if variant == "format0":
+        books = [book(2, 50, 3), book(4, 81, 2), book(8, 100, 1), book(16, 37, 1)]
+        res = [dict(type=0, begin=0, end=bs1 // 2, partition_size=16, num_classifications=6, classwords=2, books=cascade(6, 4, 0.35))]
+        maps = [([0] * channels, [0]), ([0] * channels, [0])]
+    elif variant == "format1x2":
+        books = [book(1, 9, 5), book(2, 25, 3), book(3, 27, 2), book(4, 40, 2), book(6, 64, 1)]
+        res = [dict(type=1, begin=24, end=bs1 // 2 - 100, partition_size=12, num_classifications=7, classwords=3,
+                    books=cascade(7, 5, 0.3))]
+        maps = [([0] * channels, [0]), ([0] * channels, [0])]
+    else:
+        books = [book(1, 16, 4), book(2, 64, 2), book(4, 128, 2), book(8, 60, 1)]
+        res = [dict(type=1, begin=0, end=bs1 // 2, partition_size=32, num_classifications=5, classwords=2, books=cascade(5, 4, 0.4)),
+               dict(type=0, begin=8, end=bs1 // 4, partition_size=8, num_classifications=4, classwords=1, books=cascade(4, 4, 0.4))]
+        mux = [i % 2 for i in range(channels)]
+        maps = [(mux, [0, 1]), (mux, [0, 1])]
+    # the class codebook's vector length only matters to the host's bit reader; books here always have a value table
+    return VqSpec(books, res, maps)
