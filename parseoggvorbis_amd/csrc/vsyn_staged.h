@@ -49,6 +49,26 @@ __device__ __forceinline__ uint32_t run_class(const ConstHeader* H, const vsyn_p
   return 0;
 }
 
+// The same decision from a bitmap (bit q = packet q of the segment is a valid long block), for segments of up to
+// LAYOUT_BITMAP_PACKETS packets: pass B sets the bits while it has the packet descriptors in registers, so that classifying a
+// run is a few LDS words instead of a serial walk over R+1 descriptors in global memory (which was most of this kernel's time,
+// and this kernel's workgroups sit on wave slots the synthesis kernel of the previous submit is waiting for).
+#define LAYOUT_BITMAP_PACKETS 65536u
+__device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_t qa, uint32_t qb, uint32_t carry_n, uint32_t ok_mask) {
+  if (!ok_mask) return 0;
+  bool all_long = !(qa == 0 && carry_n);
+  const uint32_t lo = qa ? qa - 1 : 0;  // one-packet halo
+  for (uint32_t w = lo >> 5; all_long && w <= ((qb - 1u) >> 5); ++w) {
+    uint32_t need = 0xFFFFFFFFu;
+    if (w == (lo >> 5)) need &= 0xFFFFFFFFu << (lo & 31u);
+    if (w == ((qb - 1u) >> 5)) need &= 0xFFFFFFFFu >> (31u - ((qb - 1u) & 31u));
+    all_long = (bits[w] & need) == need;
+  }
+  if (all_long && (ok_mask & 1u)) return 1;
+  if (ok_mask & 2u) return 2;
+  return 0;
+}
+
 __global__ void __launch_bounds__(256)
 vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet* __restrict__ pk, uint32_t S,
                    const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
@@ -86,6 +106,10 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
 
   __shared__ AbsScan s_abs[256];
   __shared__ uint64_t s_res[256];
+  __shared__ uint32_t s_longbits[LAYOUT_BITMAP_PACKETS / 32u];
+  const bool use_bits = num <= LAYOUT_BITMAP_PACKETS;
+  if (use_bits)
+    for (uint32_t w = t; w < (num + 31u) / 32u; w += 256) s_longbits[w] = 0u;
   __shared__ int64_t s_abs_end;
   __shared__ uint32_t s_last_n;
 
@@ -212,6 +236,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       pi.own = own;
       pi.used = used;
       info[p] = pi;
+      if (use_bits && mode_ok && lng) atomicOr(&s_longbits[q >> 5], 1u << (q & 31u));
       seg_of_pkt[p] = g;
       if (emit_len) emit_len[p] = emit;
       if (q == num - 1) {
@@ -232,7 +257,9 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     const uint32_t nruns = (num + R - 1) / R;
     for (uint32_t r = t; r < runs_per_seg; r += 256) {
       const uint32_t qa = r * R, qb2 = min(num, qa + R);
-      const uint32_t cls = r < nruns ? run_class(H, spk, qa, qb2, carry_n, fused_ok) : 0xFFu;  // 0xFF: no such run
+      const uint32_t cls = r >= nruns ? 0xFFu  // 0xFF: no such run
+                           : use_bits ? run_class_bits(s_longbits, qa, qb2, carry_n, fused_ok)
+                                      : run_class(H, spk, qa, qb2, carry_n, fused_ok);
       run_cls[(size_t)g * runs_per_seg + r] = (uint8_t)cls;  // the fused kernels read this instead of re-deriving it
       if (r >= nruns || cls) continue;
       const bool prev_fast = qa > 0 && run_class(H, spk, qa - R, qa, carry_n, fused_ok) != 0;
