@@ -117,25 +117,49 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   const uint32_t qb = min(num, t * per), qe = min(num, qb + per);
   const vsyn_packet* spk = pk + sg.first_packet;
 
-  auto block_n = [&](uint32_t q) -> uint32_t {
-    uint32_t m = spk[q].mode;
-    return (m < H->num_modes && H->mode_blockflag[m]) ? H->bs[1] : H->bs[0];
-  };
+  // mode -> (block flag, mapping) from LDS, and — when a thread has few packets — its descriptors loaded up front in one
+  // burst and kept in registers for both passes: the kernel is a chain of small dependent loads otherwise, and while it
+  // runs its workgroups hold wave slots of 64 CUs
+  __shared__ uint8_t s_bf[VSYN_MAX_TABLES], s_mm[VSYN_MAX_TABLES];
+  if (t < VSYN_MAX_TABLES) {
+    s_bf[t] = H->mode_blockflag[t];
+    s_mm[t] = H->mode_mapping[t];
+  }
+  constexpr uint32_t KEEP = 8;
+  const bool keep = per <= KEEP;
+  vsyn_packet kq[KEEP];
+  if (keep) {
+#pragma unroll
+    for (uint32_t j = 0; j < KEEP; ++j)
+      if (qb + j < qe) kq[j] = spk[qb + j];
+  }
+  const uint32_t num_modes = H->num_modes, bs0 = H->bs[0], bs1 = H->bs[1];
+  uint32_t carry_prev_mode = 0xFFFFFFFFu;  // mode of packet qb-1 (for the block size before this thread's first packet)
+  if (qb > 0 && qb < num) carry_prev_mode = spk[qb - 1].mode;
+  __syncthreads();
+  auto n_of_mode = [&](uint32_t m) -> uint32_t { return (m < num_modes && s_bf[m]) ? bs1 : bs0; };
+  auto block_n = [&](uint32_t q) -> uint32_t { return n_of_mode(spk[q].mode); };
 
   // pass A: per-thread aggregate
   AbsScan agg = {0, 0};
   uint64_t res = 0;
   {
-    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? block_n(qb - 1) : 0);
-    for (uint32_t q = qb; q < qe; ++q) {
-      uint32_t n = block_n(q);
+    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? n_of_mode(carry_prev_mode) : 0);
+    auto step_a = [&](const vsyn_packet& k) {
+      const uint32_t n = n_of_mode(k.mode);
       AbsScan e;
-      int64_t gr = spk[q].granule;
-      e.set = gr >= 0;
-      e.val = e.set ? gr : (prev_n ? (int64_t)(prev_n / 4 + n / 4) : 0);
+      e.set = k.granule >= 0;
+      e.val = e.set ? k.granule : (prev_n ? (int64_t)(prev_n / 4 + n / 4) : 0);
       agg = abs_combine(agg, e);
       res += (uint64_t)C * (n / 2);
       prev_n = n;
+    };
+    if (keep) {
+#pragma unroll
+      for (uint32_t j = 0; j < KEEP; ++j)
+        if (qb + j < qe) step_a(kq[j]);
+    } else {
+      for (uint32_t q = qb; q < qe; ++q) step_a(spk[q]);
     }
   }
   // exclusive scan over the 256 thread aggregates: wave-level shuffles, then the 4 wave totals through LDS
@@ -188,15 +212,14 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     AbsScan pre = s_abs[t];
     int64_t abs_before = pre.set ? pre.val : abs0 + pre.val;
     uint64_t res_off = sg.residue_off + s_res[t];
-    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? block_n(qb - 1) : 0);
-    for (uint32_t q = qb; q < qe; ++q) {
+    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? n_of_mode(carry_prev_mode) : 0);
+    auto step_b = [&](uint32_t q, const vsyn_packet& k) {
       const uint32_t p = sg.first_packet + q;
-      const vsyn_packet k = spk[q];
       PktInfo pi = {};
-      const bool mode_ok = k.mode < H->num_modes;
+      const bool mode_ok = k.mode < num_modes;
       if (!mode_ok) raise_status(status, VSYN_ST_BAD_MODE, p);
-      const uint32_t lng = mode_ok && H->mode_blockflag[k.mode] ? 1u : 0u;
-      const uint32_t n = H->bs[lng];
+      const uint32_t lng = mode_ok && s_bf[k.mode] ? 1u : 0u;
+      const uint32_t n = lng ? bs1 : bs0;
       const uint32_t L = prev_n ? prev_n / 4 + n / 4 : 0;
       int64_t abs_after = abs_before + L;
       uint32_t emit = L;
@@ -224,7 +247,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       pi.n = (uint16_t)n;
       pi.lng = (uint8_t)lng;
       pi.widx = lng ? (uint8_t)((k.prev_long ? 1 : 0) | (k.next_long ? 2 : 0)) : 0;
-      pi.mapping = mode_ok ? H->mode_mapping[k.mode] : 0;
+      pi.mapping = mode_ok ? s_mm[k.mode] : 0;
       pi.bad = bad ? 1 : 0;
       const uint32_t chan_mask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
       uint32_t own = k.floor_used & chan_mask, used = own;
@@ -246,6 +269,13 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       abs_before = abs_after;
       res_off += (uint64_t)C * (n / 2);
       prev_n = n;
+    };
+    if (keep) {
+#pragma unroll
+      for (uint32_t j = 0; j < KEEP; ++j)
+        if (qb + j < qe) step_b(qb + j, kq[j]);
+    } else {
+      for (uint32_t q = qb; q < qe; ++q) step_b(q, spk[q]);
     }
   }
   __syncthreads();
