@@ -386,29 +386,51 @@ vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const uint3
     uint64_t flags_lo = 3;
     uint32_t flag_64 = 0;
     bool bad = false;
-    for (uint32_t i = 2; i < posts; ++i) {
-      const uint4 kq = *(const uint4*)&fc->pk[i];
+    // one post: kq = its constants (neighbour indices, dx, 1/adx). Selects, no branches (the body ran as ~120 instructions
+    // of exec-mask juggling per post; at two waves per SIMD every instruction of it costs ~8 cycles).
+    auto step = [&](uint32_t i, const uint4 kq) -> bool {
       const uint32_t lo = kq.x & 0xFFFFu, hi = kq.x >> 16;
       const uint32_t val = s_fy[i][t];  // coded value; overwritten below by the amplitude
-      const uint32_t predicted = predict_post(s_fy[lo][t], s_fy[hi][t], kq.y & 0xFFFFu, kq.y >> 16, __uint_as_float(kq.z));
-      if (predicted > range) {  // hpp:536
-        bad = true;
-        break;
-      }
-      const uint32_t high_room = range - predicted, low_room = predicted;
+      const uint32_t ylo = s_fy[lo][t], yhi = s_fy[hi][t];
+      const uint32_t dxi = kq.y & 0xFFFFu, adx = kq.y >> 16;
+      // predict_post() with its rare integer-divide path taken only if some lane needs it (wave-uniform branch)
+      const bool up = yhi >= ylo;
+      const uint32_t ady = up ? yhi - ylo : ylo - yhi;
+      const uint32_t prod = ady * dxi;
+      uint32_t off = (uint32_t)(((float)prod + 0.5f) * __uint_as_float(kq.z));
+      if (__any(prod >= (1u << 21))) off = prod >= (1u << 21) ? prod / adx : off;
+      const uint32_t predicted = up ? ylo + off : ylo - off;
+      const bool ok = predicted <= range;  // hpp:536
+      const uint32_t pr = ok ? predicted : 0u;
+      const uint32_t high_room = range - pr, low_room = pr;
       const uint32_t room = min(high_room, low_room) * 2;
-      uint32_t f;
-      if (val == 0) {
-        f = predicted;
-      } else {
-        flags_lo |= (1ull << lo) | (1ull << hi);  // lo, hi < i <= 64
-        if (i < 64) flags_lo |= 1ull << i; else flag_64 = 1;
-        if (val >= room)
-          f = high_room > low_room ? val - low_room + predicted : predicted - val + high_room - 1;
-        else
-          f = (val & 1u) ? predicted - (val + 1) / 2 : predicted + val / 2;
-      }
+      const uint32_t big = high_room > low_room ? val - low_room + pr : pr - val + high_room - 1;
+      const uint32_t small = (val & 1u) ? pr - (val + 1) / 2 : pr + val / 2;
+      const uint32_t f = val == 0 ? pr : (val >= room ? big : small);
+      const uint64_t touched = (1ull << lo) | (1ull << hi) | (i < 64 ? 1ull << i : 0ull);  // lo, hi < i <= 64
+      flags_lo |= val != 0 ? touched : 0ull;
+      flag_64 |= (val != 0 && i >= 64) ? 1u : 0u;
       s_fy[i][t] = f;
+      return ok;
+    };
+    // When every active row of the wavefront uses the same floor (always, unless block sizes alternate inside the 64 rows) the
+    // per-post constants are wave-uniform: read them through the scalar unit (constant address space -> s_load, scalar cache)
+    // instead of 64 identical per-lane loads per post — those loads, not the LDS chain, set this kernel's pace.
+    const uint64_t fc_bits = (uint64_t)(uintptr_t)fc;
+    const uint64_t fc_first = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)fc_bits) |
+                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fc_bits >> 32)) << 32);
+    if (__all(fc_bits == fc_first)) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      typedef const __attribute__((address_space(4))) u32x4* const_pk;
+      const FloorConst* fcu = (const FloorConst*)(uintptr_t)fc_first;
+      const uint32_t posts_u = __builtin_amdgcn_readfirstlane(posts);
+      for (uint32_t i = 2; i < posts_u && !bad; ++i) {
+        const u32x4 w = *(const_pk)(uintptr_t)&fcu->pk[i];
+        if (!step(i, make_uint4(w.x, w.y, w.z, w.w))) bad = true;
+      }
+    } else {
+      for (uint32_t i = 2; i < posts && !bad; ++i)
+        if (!step(i, *(const uint4*)&fc->pk[i])) bad = true;
     }
     if (bad) {
       raise_status(status, VSYN_ST_FLOOR_RANGE, p);
