@@ -254,6 +254,24 @@ def main():
             cpu = {"value": round(len(hp) * reps / t_cpu, 1), "unit": "packets/s", "cores": 1, "kind": "port",
                    "sample": "%d streams x %d packets of the same batch, oracle/liboracle.so (gcc -O2), %d repetitions, %.1f s"
                              % (ns, b["ppk"], reps, t_cpu)}
+            # the reference's own src/mdct.cpp, built from its sources into oracle/_ref (when present on this box): IMDCT only
+            try:
+                from oracle import oracle_binding as ob
+                if ob.have_ref():
+                    n = spec.blocksize1
+                    xin = np.ascontiguousarray(hr[:4096 * (n // 2)].reshape(-1, n // 2))
+                    yout = np.zeros((xin.shape[0], n), np.float32)
+                    r_reps, r_t = 0, 0.0
+                    while r_t < 3.0:
+                        c0 = time.perf_counter()
+                        ob.ref().ref_mdct_backward_batch(n, xin.shape[0], xin.ctypes.data, yout.ctypes.data)
+                        r_t += time.perf_counter() - c0
+                        r_reps += 1
+                    cpu["reference_mdct_backward"] = {"us_per_block": round(r_t / (r_reps * xin.shape[0]) * 1e6, 3), "n": n, "cores": 1,
+                                                      "kind": "reference", "sample": "%d blocks x %d repetitions, oracle/_ref/libref_shim.so "
+                                                      "(the reference's src/mdct.cpp, g++ -O2)" % (xin.shape[0], r_reps)}
+            except Exception as exc:  # the baseline legs never take the bench down
+                cpu["reference_mdct_backward"] = {"error": str(exc)[:200]}
     elif b is None and rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle_binding as ob
         hx = x.cpu().numpy()
