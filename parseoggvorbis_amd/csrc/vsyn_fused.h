@@ -892,7 +892,7 @@ static inline void fused_tables_destroy(FusedTables* ft) {
 }
 
 static inline const char* fused_kernel_name(const ConstHeader&) { return "vsyn_fused_kernel"; }
-static inline const char* fused_imdct_kernel_name(uint32_t) { return "vsyn_imdct_plain_kernel"; }
+static inline const char* fused_imdct_kernel_name(uint32_t) { return "vsyn_imdct_wave_kernel"; }
 
 // run length: as few runs as fill the chip once (halo overhead is 1/R), never below 4
 static inline uint32_t fused_pick_run_len(const FusedTables& ft, uint32_t S, uint32_t channels, uint32_t max_seg_packets, int num_cus) {
@@ -916,8 +916,93 @@ static inline hipError_t fused_launch(const ConstHeader& H, const FusedTables& f
 
 // runs with short blocks / window switches / a carry-in: same grid, every wave of a run the long kernel took idles out
 
-static inline hipError_t fused_imdct_launch(const ConstHeader&, const uint8_t*, const FusedTables&, int, uint32_t, uint32_t,
-                                            const float*, float*, hipStream_t, bool* done) {
+// ------------------------------------------------------------------------------------------------
+// IMDCT only (BASELINE config 2; vsyn_imdct_device): in [count][n/2] -> out [count][n], one WAVEFRONT per block for the two
+// block sizes the fused paths know (n = 2048: FFT-512 in registers + LDS exchanges as in fused_run; n = 256: FFT-64 across the
+// lanes as in the mixed path). What mdct_backward (mdct.cpp:433-527) computes, by the DCT-IV route:
+//   u[2m] = Re d[m], u[M-1-2m] = -Im d[m] (M = n/2, d = post-rotated FFT output), then
+//   y[i] = u[i + M/2] (i < M/2),  -u[3M/2 - 1 - i] (M/2 <= i < 3M/2),  -u[i - 3M/2] (i >= 3M/2)
+// u goes through the wave's LDS image once so that the n outputs leave as contiguous 16-byte stores. Twiddles are read from
+// the (L2-resident) table image in global memory: a batch may be far too small to pay for staging 27 KB per workgroup.
+// ------------------------------------------------------------------------------------------------
+#define IMDCT_WAVES 4
+template <int LONG>
+__global__ void __launch_bounds__(IMDCT_WAVES * 64) vsyn_imdct_wave_kernel(const FusedLdsImage* __restrict__ T, uint32_t count,
+                                                                           const float* __restrict__ in, float* __restrict__ out) {
+  __shared__ float2 s_x[IMDCT_WAVES][FUSED_XSLOTS];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  float2* xb = s_x[wave];
+  float* u = (float*)xb;
+  constexpr uint32_t M = LONG ? 1024u : 128u;
+  for (uint32_t blk = blockIdx.x * IMDCT_WAVES + wave; blk < count; blk += gridDim.x * IMDCT_WAVES) {
+    const float2* src = (const float2*)(in + (size_t)blk * M) + lane;
+    float* y = out + (size_t)blk * (2u * M);
+    if (LONG) {
+      float2 r[8], z[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) r[t] = src[64 * t];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float im = __shfl(r[7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
+        z[t] = cmulf(f2(r[t].x, im), T->pre[t][lane]);
+      }
+      fft512_wave(z, xb, T, lane);
+      const uint32_t kappa = ((lane & 7u) << 3) | (lane >> 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the exchange image is about to be reused for u
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float2 d = cmulf(z[k], T->post[k][lane]);
+        const uint32_t m = kappa + 64u * k;
+        u[2u * m] = d.x;
+        u[M - 1u - 2u * m] = -d.y;
+      }
+    } else {
+      const float2 r = src[0];
+      const float im = __shfl(r.y, 63 - (int)lane);  // X[127 - 2k] lives in lane 63-k
+      float2 z = cmulf(f2(r.x, im), T->pre_s[lane]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {  // radix-2 decimation in frequency across lanes: partner l ^ d, d = 32 .. 1
+        const int d = 32 >> i;
+        const float ox = __shfl_xor(z.x, d), oy = __shfl_xor(z.y, d);
+        const bool upper = (lane & (uint32_t)d) != 0;
+        const float2 sum = f2(z.x + ox, z.y + oy);
+        const float2 dif = cmulf(f2(ox - z.x, oy - z.y), T->tws[i][lane]);  // (lower - upper) * W, evaluated in the upper lane
+        z = upper ? dif : sum;
+      }
+      const float2 d = cmulf(z, T->post_s[lane]);
+      const uint32_t m = bitrev6(lane);
+      u[2u * m] = d.x;
+      u[M - 1u - 2u * m] = -d.y;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: u is complete once its own LDS writes have landed
+    // y in runs of 4: the three ranges of the definition are multiples of 4 long, so a run never straddles two of them
+    for (uint32_t i4 = lane; i4 < 2u * M / 4u; i4 += 64) {
+      const uint32_t i = 4u * i4;
+      float4 v;
+      if (i < M / 2u) {
+        v = *(const float4*)&u[i + M / 2u];
+      } else if (i < 3u * M / 2u) {
+        const float4 w = *(const float4*)&u[3u * M / 2u - 4u - i];  // u[3M/2-1-i-3 .. 3M/2-1-i], reversed below
+        v = make_float4(-w.w, -w.z, -w.y, -w.x);
+      } else {
+        const float4 w = *(const float4*)&u[i - 3u * M / 2u];
+        v = make_float4(-w.x, -w.y, -w.z, -w.w);
+      }
+      *(float4*)&y[i] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // u has been read before the next block reuses the image
+  }
+}
+
+static inline hipError_t fused_imdct_launch(const ConstHeader& H, const uint8_t*, const FusedTables& ft, int, uint32_t n, uint32_t count,
+                                            const float* d_in, float* d_out, hipStream_t s, bool* done) {
   *done = false;
-  return hipSuccess;
+  if (!ft.d_lds) return hipSuccess;  // no table image for this setup (it exists iff blocksize1 is 2048): the generic kernel takes it
+  if ((((uintptr_t)d_in) & 7u) || (((uintptr_t)d_out) & 15u)) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)count + IMDCT_WAVES - 1) / IMDCT_WAVES, 256u * 8u);
+  if (n == 2048 && H.bs[1] == 2048) vsyn_imdct_wave_kernel<1><<<grid, IMDCT_WAVES * 64, 0, s>>>(ft.d_lds, count, d_in, d_out);
+  else if (n == 256 && H.bs[0] == 256) vsyn_imdct_wave_kernel<0><<<grid, IMDCT_WAVES * 64, 0, s>>>(ft.d_lds, count, d_in, d_out);
+  else return hipSuccess;
+  *done = true;
+  return hipGetLastError();
 }
