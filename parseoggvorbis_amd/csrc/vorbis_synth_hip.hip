@@ -93,6 +93,7 @@ struct vsyn_handle {
   uint8_t* d_const = nullptr;
   uint8_t* d_vq = nullptr;             // residue VQ stage: VqHeader, books, residues, maps, value pool (vsyn_attach_vq)
   uint32_t vq_lds_bytes = 0;           // dynamic LDS of the residue VQ kernel
+  uint32_t vq_grid = 0;                // workgroups of the VQ kernel that are resident at once (its grid: every wave walks packets)
   uint32_t last_S = 0, last_wb = 0;    // segments / workspace half of the most recent submit (vsyn_pcm_interleave_device)
   DevBuf<vsyn_vq_packet> st_vqpk;      // vsyn_submit_host_vq staging
   DevBuf<uint8_t> st_cls;
@@ -531,7 +532,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   }
   if (d_vq) {
     if (h->profile_which == 3) HIPCHK(profile_begin(h, ps, "vsyn_residue_vq_kernel"));
-    vsyn_residue_vq_kernel<<<std::min<uint32_t>(P, (uint32_t)h->num_cus * 32u), VQ_THREADS, h->vq_lds_bytes, ps>>>(
+    vsyn_residue_vq_kernel<<<std::min<uint32_t>(P, h->vq_grid), VQ_THREADS, h->vq_lds_bytes, ps>>>(
         h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
   }
   if (d_vq && h->profile_which == 3) HIPCHK(profile_end(h, ps));
@@ -636,6 +637,10 @@ int vsyn_attach_vq(vsyn_handle* h, const vsyn_vq_setup* vq, const char** err) {
   {
     const VqHeader* vh = (const VqHeader*)block.data();
     h->vq_lds_bytes = vh->max_slots / 2u * (uint32_t)sizeof(uint32_t) + 16u;
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vsyn_residue_vq_kernel, VQ_THREADS, h->vq_lds_bytes));
+    if (const char* e = getenv("VSYN_VQ_WG_PER_CU")) per_cu = atoi(e);
+    h->vq_grid = (uint32_t)h->num_cus * (uint32_t)std::max(per_cu, 1);
   }
   return VSYN_OK;
 }
