@@ -636,7 +636,8 @@ int vsyn_attach_vq(vsyn_handle* h, const vsyn_vq_setup* vq, const char** err) {
   HIPCHK(hipMemcpy(h->d_vq, block.data(), block.size(), hipMemcpyHostToDevice));
   {
     const VqHeader* vh = (const VqHeader*)block.data();
-    h->vq_lds_bytes = vh->max_slots / 2u * (uint32_t)sizeof(uint32_t) + 16u;
+    uint32_t lds_off[7];
+    h->vq_lds_bytes = vq_lds_layout(vh->max_slots, vh->max_classes, lds_off);
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vsyn_residue_vq_kernel, VQ_THREADS, h->vq_lds_bytes));
     if (const char* e = getenv("VSYN_VQ_WG_PER_CU")) per_cu = atoi(e);

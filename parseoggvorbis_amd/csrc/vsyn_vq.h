@@ -26,10 +26,12 @@
 #pragma once
 #include "vsyn_device.h"
 
-#define VQ_THREADS 64      /* one wavefront per packet: every synchronisation is wave-local */
+#define VQ_THREADS 64      /* one wavefront per packet: every hand-off is wave-local, no barriers */
 #define VQ_GROUP 8
 #define VQ_MAX_SLOTS 8192  /* (pass, partition, channel) slots of one submap vector; vsyn_attach_vq enforces it. The kernel's
                               dynamic LDS is sized to the largest count the attached setup can produce (fixtures: 400) */
+#define VQ_ENT_CAP 2048    /* a packet with at most this many entry numbers has them staged in LDS by direct-to-LDS loads
+                              (stereo long blocks of the fixture: ~1400); longer ones read them from global memory */
 
 struct VqBook {       // 16 bytes
   uint32_t dims, entries;
@@ -37,28 +39,55 @@ struct VqBook {       // 16 bytes
   uint32_t pad;
 };
 struct VqResidue {
-  uint32_t type, begin, end, psize, nclass, classwords, pad0, pad1;
+  uint32_t type, begin, end, psize, nclass, classwords, pass_mask, pad1;  // pass_mask bit k: some class has a codebook in pass k
   int16_t books[64 * 8];
 };
-struct VqMap {
+struct VqMap {        // all fields the per-packet code reads are dwords: they come in through the scalar cache
   uint32_t num_submaps;
+  uint32_t sub_nch[16];    // channels muxed to the submap (0: the submap is skipped, hpp:1191-1199)
+  uint32_t sub_rid[16];    // residue of the submap
+  uint32_t sub_chan4[16];  // its first four channel numbers, one per byte
   uint8_t mux[VSYN_MAX_CHANNELS];
-  uint8_t submap_residue[16];
 };
 struct VqHeader {
   uint32_t num_books, num_residues, num_maps, pad;
   uint32_t off_books, off_residues, off_maps, off_pool;  // byte offsets from the block base
   uint32_t pool_floats, total_bytes;
-  uint32_t max_slots, pad2;  // largest slot count of any submap vector at blocksize1: the kernel's dynamic LDS holds max_slots / 2 words
+  uint32_t max_slots, max_classes;  // largest slot count of any submap vector at blocksize1 / class count of any residue: LDS sizing
 };
 
+// Dynamic LDS of one workgroup (= one wavefront), shared between the host (launch) and the kernel (carving):
+//   cp    [max_classes * 8] x 8 B   per (class, pass): value table + entry count / vector length facts
+//   pp    [max_classes * 8] x u16   per (class, pass): vectors per partition (0: no codebook) — a row is the scan's four packed counts
+//   start [npj_max] x 16 B          per (partition, vector): first entry of its slot in each pass, passes 2k / 2k+1 packed 16+16
+//   ent   [VQ_ENT_CAP + 8] x u16    the packet's entry numbers
+//   vm    [max_classes] x u8        passes of the class that have a codebook
+//   cls   [npj_max] x u8            classification per (partition, vector), 0xFF: takes no part
+//   chan  [VSYN_MAX_CHANNELS] x u8  channels of the submap
+static inline __host__ __device__ uint32_t vq_align16(uint32_t x) { return (x + 15u) & ~15u; }
+static inline __host__ __device__ uint32_t vq_lds_layout(uint32_t max_slots, uint32_t max_classes, uint32_t* off /* [7] */) {
+  const uint32_t npj = max_slots / 8u;
+  uint32_t o = 0;
+  off[0] = o; o += max_classes * 64u;
+  off[1] = o; o += max_classes * 16u;
+  off[2] = o; o += npj * 16u;
+  off[3] = o; o += vq_align16((VQ_ENT_CAP + 8u) * 2u);
+  off[4] = o; o += vq_align16(max_classes);
+  off[5] = o; o += vq_align16(npj);
+  off[6] = o; o += VSYN_MAX_CHANNELS;
+  return o;
+}
+
 #ifdef __HIPCC__
-struct VqBookLds {  // per-book facts the accumulate loop needs, staged in LDS when the residue in use changes
-  uint32_t table_off;
-  uint16_t dims, per_part;   // vector length; vectors per partition = psize / dims
-  uint32_t entries;          // bits 0..23 entry count; bit 31: dims is a power of two, bits 24..28: log2(dims) then
+struct VqCp {  // per (class, pass)
+  uint32_t tab;  // float index of the value table in the pool
+  uint32_t inf;  // bits 0..15 entry count - 1; 16..19 log2(vector length) if VQ_CP_FAST; VQ_CP_* flags
 };
-#define VQ_MAX_BOOKS 256
+#define VQ_CP_FAST 0x01000000u  /* 8.6.4 layout (format 1 / 2) and a power-of-two vector length */
+typedef uint32_t vq_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t vq_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t vq_u32x2 __attribute__((ext_vector_type(2)));
+#define VQ_K __attribute__((address_space(4)))  /* wave-uniform read-only data: scalar loads */
 
 // inclusive prefix sum across the 64 lanes with DPP row shifts / broadcasts (no LDS traffic, 6 VALU steps)
 __device__ __forceinline__ uint32_t vq_wave_scan(uint32_t v) {
@@ -71,280 +100,353 @@ __device__ __forceinline__ uint32_t vq_wave_scan(uint32_t v) {
   return v;
 }
 
-// The general element -> (vector, component) mapping, out of line: format 0 (8.6.3, hpp:738-746: element w <- vector w % step,
-// component w / step), vector lengths that are not a power of two, partition tails. Returns true if an entry number is out
-// of range; add[k] = 0 for such elements and for k beyond the partition.
-__device__ __noinline__ bool vq_gather_general(float (&add)[VQ_GROUP], uint32_t type, uint32_t psize, uint32_t w0, uint32_t step, uint32_t dims,
-                                               uint32_t nent, const uint16_t* __restrict__ e0, const float* __restrict__ tab) {
-  bool bad = false;
-  for (int k = 0; k < VQ_GROUP; ++k) {
-    const uint32_t ww = w0 + k;
-    float v = 0.f;
-    if (ww < psize) {
-      uint32_t ei, li;
-      if (type == 0) {
-        li = ww / step;
-        ei = ww - li * step;
-      } else {
-        ei = ww / dims;
-        li = ww - ei * dims;
-      }
-      const uint32_t en = e0[ei];
-      if (en < nent) v = tab[(size_t)en * dims + li];
-      else bad = true;
+// Everything one submap vector needs in the accumulate phase (wave-uniform)
+struct VqSubCtx {
+  uint32_t type, psize, vch, nch, npj, parts, lim_begin, len, n2, gpp, pass_mask;
+  uint32_t chan0, chan1;
+  uint32_t ent_base;        // first entry of the submap relative to the packet's first entry
+  uint32_t poff[8];         // first entry of each pass relative to ent_base
+  uint32_t ent_shift;       // ENT_LDS: index of the packet's first entry inside s_ent
+};
+
+// The accumulate phase: a lane owns VQ_GROUP consecutive elements of one partition of one vector and adds their up-to-8
+// contributions in pass order (hpp:711) in registers. ENT_LDS: the packet's entries sit in s_ent, otherwise in eg[].
+template <bool ENT_LDS>
+__device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t lane, const bool bad, const uint32_t vused, const VqCp* s_cp,
+                                               const uint16_t* s_pp, const vq_u32x4* s_start, const uint16_t* s_ent, const uint8_t* s_vm,
+                                               const uint8_t* s_cls, const uint8_t* s_chan, const uint16_t* __restrict__ eg,
+                                               const float* __restrict__ pool, float* __restrict__ out) {
+  auto entry = [&](uint32_t i) -> uint32_t { return ENT_LDS ? (uint32_t)s_ent[X.ent_shift + i] : (uint32_t)eg[i]; };
+  const uint32_t groups = X.npj * X.gpp;
+  const bool full8 = (X.psize & (VQ_GROUP - 1u)) == 0u;
+  const uint32_t q64 = VQ_THREADS / X.gpp, r64 = VQ_THREADS - q64 * X.gpp;
+  uint32_t pj = lane / X.gpp, wq = lane - pj * X.gpp;
+  bool bad_entry = false;
+  for (uint32_t gi = lane; gi < groups; gi += VQ_THREADS) {
+    const uint32_t w0 = wq * VQ_GROUP;
+    uint32_t pc = pj, j = 0;
+    if (X.vch != 1u) {
+      pc = pj / X.vch;
+      j = pj - pc * X.vch;
     }
-    add[k] = v;
+    const uint32_t cnt_el = full8 ? (uint32_t)VQ_GROUP : min((uint32_t)VQ_GROUP, X.psize - w0);
+    float acc[VQ_GROUP];
+#pragma unroll
+    for (int k = 0; k < VQ_GROUP; ++k) acc[k] = 0.f;
+    const uint32_t c = s_cls[pj];
+    if (!bad && c != 0xFFu) {
+      const uint32_t vm = s_vm[c];
+      const vq_u32x4 st4 = s_start[pj];
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {  // pass order = order of the additions (hpp:711)
+        if (!((X.pass_mask >> ps) & 1u)) continue;  // wave-uniform: no class of this residue has a codebook here (typical for passes 3..7)
+        if (!((vm >> ps) & 1u)) continue;
+        const VqCp cp = s_cp[c * 8u + ps];
+        const uint32_t e0 = X.ent_base + X.poff[ps] + ((st4[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu);
+        const uint32_t nent1 = cp.inf & 0xFFFFu, sh = (cp.inf >> 16) & 15u;
+        float add[VQ_GROUP];
+        if ((cp.inf & VQ_CP_FAST) && cnt_el == VQ_GROUP) {
+          // out-of-range entry numbers read the zero vector at the start of the pool instead
+          if (sh >= 3u) {         // one vector covers the group's 8 elements: 8 consecutive components
+            const uint32_t en = entry(e0 + (w0 >> sh));
+            const bool ok = en <= nent1;
+            bad_entry |= !ok;
+            const float4* v4 = (const float4*)(pool + (ok ? cp.tab + (en << sh) + (w0 & ((1u << sh) - 1u)) : 0u));
+            const float4 a = v4[0], b = v4[1];
+            add[0] = a.x; add[1] = a.y; add[2] = a.z; add[3] = a.w;
+            add[4] = b.x; add[5] = b.y; add[6] = b.z; add[7] = b.w;
+          } else if (sh == 2u) {  // two vectors of 4
+            const uint32_t i0 = e0 + (w0 >> 2);
+            const uint32_t en0 = entry(i0), en1 = entry(i0 + 1u);
+            const bool ok0 = en0 <= nent1, ok1 = en1 <= nent1;
+            bad_entry |= !(ok0 && ok1);
+            const float4 a = *(const float4*)(pool + (ok0 ? cp.tab + en0 * 4u : 0u));
+            const float4 b = *(const float4*)(pool + (ok1 ? cp.tab + en1 * 4u : 0u));
+            add[0] = a.x; add[1] = a.y; add[2] = a.z; add[3] = a.w;
+            add[4] = b.x; add[5] = b.y; add[6] = b.z; add[7] = b.w;
+          } else if (sh == 1u) {  // four vectors of 2
+            const uint32_t i0 = e0 + (w0 >> 1);
+            uint32_t en[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) en[k] = entry(i0 + k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bool ok = en[k] <= nent1;
+              bad_entry |= !ok;
+              const float2 a = *(const float2*)(pool + (ok ? cp.tab + en[k] * 2u : 0u));
+              add[2 * k] = a.x;
+              add[2 * k + 1] = a.y;
+            }
+          } else {                // eight scalars
+            uint32_t en[VQ_GROUP];
+#pragma unroll
+            for (int k = 0; k < VQ_GROUP; ++k) en[k] = entry(e0 + w0 + k);
+#pragma unroll
+            for (int k = 0; k < VQ_GROUP; ++k) {
+              const bool ok = en[k] <= nent1;
+              bad_entry |= !ok;
+              add[k] = pool[ok ? cp.tab + en[k] : 0u];
+            }
+          }
+        } else {
+          // The general element -> (vector, component) mapping: format 0 (8.6.3, hpp:738-746: element w <- vector w % step,
+          // component w / step), vector lengths that are not a power of two, partition tails.
+          const uint32_t step = s_pp[c * 8u + ps];  // vectors per partition
+          const uint32_t dims = X.psize / step;
+#pragma unroll
+          for (int k = 0; k < VQ_GROUP; ++k) {
+            const uint32_t ww = w0 + k;
+            uint32_t idx = 0;
+            if (ww < X.psize) {
+              uint32_t ei, li;
+              if (X.type == 0u) {
+                li = ww / step;
+                ei = ww - li * step;
+              } else {
+                ei = ww / dims;
+                li = ww - ei * dims;
+              }
+              const uint32_t en = entry(e0 + ei);
+              if (en <= nent1) idx = cp.tab + en * dims + li;
+              else bad_entry = true;
+            }
+            add[k] = pool[idx];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < VQ_GROUP; ++k) acc[k] += add[k];
+      }
+    }
+    // store (de-interleaving format 2: element e of the interleaved vector is bin e / nch of channel e % nch, hpp:690-692)
+    const uint32_t e_first = X.lim_begin + pc * X.psize + w0;
+    const bool fmt2 = X.type == 2u;
+    if (fmt2 && X.nch == 2u && cnt_el == VQ_GROUP && !(e_first & 1u)) {  // stereo: 4 consecutive bins per channel
+      float* o0 = out + (size_t)X.chan0 * X.n2 + (e_first >> 1);
+      float* o1 = out + (size_t)X.chan1 * X.n2 + (e_first >> 1);
+      if (((uintptr_t)o0 & 15u) == 0 && ((uintptr_t)o1 & 15u) == 0) {
+        *(float4*)o0 = make_float4(acc[0], acc[2], acc[4], acc[6]);
+        *(float4*)o1 = make_float4(acc[1], acc[3], acc[5], acc[7]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o0[k] = acc[2 * k];
+          o1[k] = acc[2 * k + 1];
+        }
+      }
+    } else if (!fmt2 && cnt_el == VQ_GROUP && (((uintptr_t)(out + (size_t)s_chan[j] * X.n2 + e_first)) & 15u) == 0) {
+      float4* o = (float4*)(out + (size_t)s_chan[j] * X.n2 + e_first);
+      o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VQ_GROUP; ++k)
+        if ((uint32_t)k < cnt_el) {
+          const uint32_t e = e_first + k;
+          if (fmt2) out[(size_t)s_chan[e % X.nch] * X.n2 + e / X.nch] = acc[k];
+          else out[(size_t)s_chan[j] * X.n2 + e] = acc[k];
+        }
+    }
+    pj += q64;
+    wq += r64;
+    if (wq >= X.gpp) {
+      wq -= X.gpp;
+      ++pj;
+    }
   }
-  return bad;
+  return bad_entry;
 }
 
-// grid: a fixed number of single-wave workgroups, each walking packets p = blockIdx.x, + gridDim.x, ... (the staged tables
-// survive from packet to packet while the residue in use stays the same)
+// grid: as many single-wave workgroups as are resident at once, each walking packets p = blockIdx.x, + gridDim.x, ... (the
+// staged per-residue tables survive from packet to packet while the residue in use stays the same)
 __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ vqb, uint32_t P,
                                                                      const PktInfo* __restrict__ info, const vsyn_vq_packet* __restrict__ vqp,
                                                                      const uint8_t* __restrict__ cls_all, uint64_t num_cls,
                                                                      const uint16_t* __restrict__ ent_all, uint64_t num_ent,
                                                                      float* __restrict__ residue, DevStatus* __restrict__ status) {
-  extern __shared__ uint32_t s_start[];  // [4][npj]: first entry of slot (pass, pj) relative to the pass's first entry; passes 2k, 2k+1 packed 16+16
-  __shared__ VqBookLds s_book[VQ_MAX_BOOKS];
-  __shared__ __attribute__((aligned(16))) int16_t s_books[64 * 8];
-  __shared__ uint32_t s_pass_off[9];
-  __shared__ uint8_t s_chan[VSYN_MAX_CHANNELS];
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
   const ConstHeader* H = hdr_of(cb);
-  const VqHeader* VH = (const VqHeader*)vqb;
+  const VQ_K VqHeader* VH = (const VQ_K VqHeader*)(uintptr_t)vqb;
   const uint32_t C = H->channels, lane = threadIdx.x;
+  uint32_t lo[7];
+  (void)vq_lds_layout(VH->max_slots, VH->max_classes, lo);
+  VqCp* s_cp = (VqCp*)(s_raw + lo[0]);
+  uint16_t* s_pp = (uint16_t*)(s_raw + lo[1]);
+  vq_u32x4* s_start = (vq_u32x4*)(s_raw + lo[2]);
+  uint16_t* s_ent = (uint16_t*)(s_raw + lo[3]);
+  uint8_t* s_vm = s_raw + lo[4];
+  uint8_t* s_cls = s_raw + lo[5];
+  uint8_t* s_chan = s_raw + lo[6];
   const VqBook* books = (const VqBook*)(vqb + VH->off_books);
   const float* pool = (const float*)(vqb + VH->off_pool);
-  const uint32_t nbooks = min(VH->num_books, (uint32_t)VQ_MAX_BOOKS);
+  const uint32_t max_slots = VH->max_slots;
   uint32_t staged_residue = 0xFFFFFFFFu, staged_map = 0xFFFFFFFFu, staged_sub = 0xFFFFFFFFu;
-
   for (uint32_t p = blockIdx.x; p < P; p += gridDim.x) {
-    const PktInfo pi = info[p];
-    if (pi.bad || pi.n == 0) continue;  // flagged by the layout kernel; nothing downstream reads this packet's residue
-    const uint32_t n2 = pi.n / 2u;
-    const VqMap* mp = (const VqMap*)(vqb + VH->off_maps) + pi.mapping;
-    const vsyn_vq_packet vp = vqp[p];
-    bool bad = vp.entry_off + vp.num_entries > num_ent;
-    const uint16_t* ent = ent_all + vp.entry_off;
-    uint32_t cls_cur = vp.cls_off, ent_cur = 0;  // cursors over the packet's classification bytes / entries, submap after submap
-    float* const out = residue + pi.res_off;
+    // wave-uniform descriptors through the scalar cache (the layout kernel / the copies that wrote them finished before this launch)
+    const vq_u32x8 iw = *(const VQ_K vq_u32x8*)(uintptr_t)(info + p);  // PktInfo
+    const uint32_t pn = iw[6] & 0xFFFFu, pmapping = iw[7] & 0xFFu, pbad = (iw[7] >> 8) & 0xFFu, pused = iw[4];
+    if (pbad || pn == 0) continue;  // flagged by the layout kernel; nothing downstream reads this packet's residue
+    const uint32_t n2 = pn / 2u;
+    const vq_u32x4 vw = *(const VQ_K vq_u32x4*)(uintptr_t)(vqp + p);   // vsyn_vq_packet
+    const uint64_t entry_off = (uint64_t)vw[0] | ((uint64_t)vw[1] << 32);
+    const uint32_t pkt_entries = vw[2];
+    const VQ_K VqMap* mp = (const VQ_K VqMap*)(uintptr_t)(vqb + VH->off_maps) + pmapping;
+    bool bad = entry_off + pkt_entries > num_ent;
+    const uint16_t* ent = ent_all + entry_off;
+    uint32_t cls_cur = vw[3], ent_cur = 0;  // cursors over the packet's classification bytes / entries, submap after submap
+    float* const out = residue + ((uint64_t)iw[0] | ((uint64_t)iw[1] << 32));
 
-    for (uint32_t s = 0; s < mp->num_submaps; ++s) {
-      // channels of this submap, in channel order (hpp:1191-1199)
-      uint32_t nch = 0;
-      for (uint32_t ch = 0; ch < C; ++ch) nch += mp->mux[ch] == s;
+    // entries -> LDS, 16 bytes per lane and instruction straight into s_ent (no registers; waited for before the accumulate phase).
+    // The 16-byte pieces are aligned, so the first and the last one stay inside the pages that hold the packet's entries.
+    const bool ent_lds = !bad && pkt_entries != 0u && pkt_entries <= (uint32_t)VQ_ENT_CAP;
+    uint32_t ent_shift = 0;
+    if (ent_lds) {
+      const uintptr_t a0 = (uintptr_t)ent, a16 = a0 & ~(uintptr_t)15;
+      ent_shift = (uint32_t)(a0 - a16) / 2u;
+      const uint32_t pieces = (ent_shift + pkt_entries + 7u) / 8u;
+      for (uint32_t c0 = 0; c0 < pieces; c0 += VQ_THREADS)
+        if (c0 + lane < pieces)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a16 + (uintptr_t)(c0 + lane) * 16u),
+                                           (__attribute__((address_space(3))) void*)(s_ent + c0 * 8u), 16, 0, 0);
+    }
+
+    const uint32_t num_submaps = mp->num_submaps;
+    for (uint32_t s = 0; s < num_submaps; ++s) {
+      const uint32_t nch = mp->sub_nch[s];
       if (nch == 0) continue;
-      const uint32_t rid = mp->submap_residue[s];
+      const uint32_t rid = mp->sub_rid[s], chan4 = mp->sub_chan4[s];
       const VqResidue* r = (const VqResidue*)(vqb + VH->off_residues) + rid;
-      const bool fmt2 = r->type == 2;
-      const uint32_t vch = fmt2 ? 1u : nch;            // vectors decoded side by side (format 2: one interleaved vector)
-      const uint32_t len = fmt2 ? nch * n2 : n2;       // hpp:687-688
-      const uint32_t psize = r->psize;
-      const uint32_t lim_begin = min(r->begin, len), lim_end = min(r->end, len);  // hpp:696-698
-      const uint32_t parts = lim_end > lim_begin ? (lim_end - lim_begin) / psize : 0u;
-      const uint32_t npj = parts * vch;                // (partition, vector) pairs; slot = (pass, pj), pj = pc * vch + j
-      __syncthreads();  // (single wave: orders this wave's LDS traffic around the table updates)
-      if (staged_map != pi.mapping || staged_sub != s) {
+      const vq_u32x8 rw = *(const VQ_K vq_u32x8*)(uintptr_t)r;  // type, begin, end, psize, nclass, classwords, pass_mask
+      VqSubCtx X;
+      X.type = rw[0];
+      X.psize = rw[3];
+      X.pass_mask = rw[6];
+      const uint32_t nclass = rw[4];
+      const bool fmt2 = X.type == 2u;
+      X.nch = nch;
+      X.n2 = n2;
+      X.vch = fmt2 ? 1u : nch;             // vectors decoded side by side (format 2: one interleaved vector)
+      X.len = fmt2 ? nch * n2 : n2;        // hpp:687-688
+      const uint32_t lim_begin = min(rw[1], X.len), lim_end = min(rw[2], X.len);  // hpp:696-698
+      X.lim_begin = lim_begin;
+      X.parts = lim_end > lim_begin ? (lim_end - lim_begin) / X.psize : 0u;
+      X.npj = X.parts * X.vch;             // (partition, vector) pairs; slot = (pass, pj), pj = pc * vch + j
+      X.gpp = (X.psize + VQ_GROUP - 1) / VQ_GROUP;  // element groups per partition
+      X.chan0 = chan4 & 0xFFu;
+      X.chan1 = (chan4 >> 8) & 0xFFu;
+      X.ent_base = ent_cur;
+      X.ent_shift = ent_shift;
+      asm volatile("" ::: "memory");  // (single wave: LDS operations execute in order; this only pins the compiler)
+      if (staged_map != pmapping || staged_sub != s) {
         if (lane == 0) {
           uint32_t k = 0;
           for (uint32_t ch = 0; ch < C; ++ch)
             if (mp->mux[ch] == s) s_chan[k++] = (uint8_t)ch;
         }
-        staged_map = pi.mapping;
+        staged_map = pmapping;
         staged_sub = s;
       }
       if (staged_residue != rid) {
-        for (uint32_t i = lane; i < 64 * 8; i += VQ_THREADS) s_books[i] = r->books[i];
-        for (uint32_t i = lane; i < nbooks; i += VQ_THREADS) {
-          const VqBook bk = books[i];
-          VqBookLds e;
-          e.table_off = bk.table_off;
-          e.dims = (uint16_t)bk.dims;
-          e.per_part = (uint16_t)(bk.dims ? psize / bk.dims : 0u);
-          e.entries = bk.entries & 0x00FFFFFFu;
-          if (bk.dims && (bk.dims & (bk.dims - 1u)) == 0u) e.entries |= 0x80000000u | ((31u - (uint32_t)__clz((int)bk.dims)) << 24);
-          s_book[i] = e;
+        for (uint32_t i = lane; i < nclass * 8u; i += VQ_THREADS) {
+          const int book = r->books[i];
+          VqCp e;
+          e.tab = 0;
+          e.inf = 0;
+          uint32_t per_part = 0;
+          if (book >= 0) {
+            const VqBook bk = books[book];
+            per_part = X.psize / bk.dims;
+            e.tab = bk.table_off;
+            e.inf = (bk.entries - 1u) & 0xFFFFu;
+            if (X.type != 0u && (bk.dims & (bk.dims - 1u)) == 0u) e.inf |= VQ_CP_FAST | ((31u - (uint32_t)__clz((int)bk.dims)) << 16);
+          }
+          s_cp[i] = e;
+          s_pp[i] = (uint16_t)per_part;
+        }
+        for (uint32_t c = lane; c < nclass; c += VQ_THREADS) {
+          uint32_t m = 0;
+          for (uint32_t ps = 0; ps < 8; ++ps) m |= (r->books[c * 8u + ps] >= 0 ? 1u : 0u) << ps;
+          s_vm[c] = (uint8_t)m;
         }
         staged_residue = rid;
       }
-      const uint8_t* chan = s_chan;
       const uint8_t* cls = cls_all + cls_cur;
-      if ((uint64_t)cls_cur + (uint64_t)npj > num_cls || 8u * npj > VH->max_slots) bad = true;
-      __syncthreads();
+      if ((uint64_t)cls_cur + (uint64_t)X.npj > num_cls || 8u * X.npj > max_slots) bad = true;
+      asm volatile("" ::: "memory");
       uint32_t vused = 0;  // bit j: vector j takes part (format 2: always, hpp:685-694; else floor_output_used, hpp:729)
-      for (uint32_t j = 0; j < vch; ++j)
-        if (fmt2 || ((pi.used >> chan[j]) & 1u)) vused |= 1u << j;
+      if (fmt2) vused = 1u;
+      else
+        for (uint32_t j = 0; j < X.vch; ++j)
+          if ((pused >> s_chan[j]) & 1u) vused |= 1u << j;
 
       // ---- entries per slot + exclusive scan in decode order (pass, partition, vector) ----
       // A lane takes one (partition, vector) pair and its 8 passes; two passes share a 32-bit word (a pass holds at most
-      // len <= 65535 entries... enforced: 16 bits each), so four DPP scans cover the eight per-pass prefix sums.
+      // len <= 65535 entries: 16 bits each), so four DPP scans cover the eight per-pass prefix sums. A row of s_pp is
+      // exactly the lane's four packed counts.
       uint32_t carry[4] = {0, 0, 0, 0};
-      for (uint32_t base = 0; base < npj && !bad; base += VQ_THREADS) {
+      bool bad_cls = false;
+      for (uint32_t base = 0; base < X.npj && !bad; base += VQ_THREADS) {
         const uint32_t pj = base + lane;
-        uint32_t cnt[4] = {0, 0, 0, 0};
-        if (pj < npj) {
-          const uint32_t pc = pj / vch, j = pj - pc * vch;
-          const uint32_t c = cls[(size_t)j * parts + pc];
-          if (((vused >> j) & 1u) && c < r->nclass) {
-            const uint4 bw = *(const uint4*)&s_books[c * 8];  // the class's 8 books, one LDS read
-            const uint32_t w[4] = {bw.x, bw.y, bw.z, bw.w};
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-              const int book = (int16_t)(w[ps >> 1] >> (16 * (ps & 1)));
-              if (book >= 0) cnt[ps >> 1] += (uint32_t)s_book[book].per_part << (16 * (ps & 1));
+        vq_u32x4 cnt = {0, 0, 0, 0};
+        if (pj < X.npj) {
+          uint32_t pc = pj, j = 0;
+          if (X.vch != 1u) {
+            pc = pj / X.vch;
+            j = pj - pc * X.vch;
+          }
+          uint32_t c = 0xFFu;
+          if ((vused >> j) & 1u) {
+            c = cls[(size_t)j * X.parts + pc];
+            if (c >= nclass) {
+              bad_cls = true;
+              c = 0xFFu;
             }
           }
+          s_cls[pj] = (uint8_t)c;
+          if (c != 0xFFu) cnt = *(const vq_u32x4*)&s_pp[c * 8u];
         }
+        vq_u32x4 st;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const uint32_t inc = vq_wave_scan(cnt[k]);
-          if (pj < npj) s_start[k * npj + pj] = carry[k] + inc - cnt[k];
+          st[k] = carry[k] + inc - cnt[k];
           carry[k] += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
+        if (pj < X.npj) s_start[pj] = st;
       }
-      if (lane == 0) {
-        uint32_t run = 0;
+      if (__any(bad_cls)) {
+        if (lane == 0) raise_status(status, VSYN_ST_BAD_VQ, p);
+      }
+      uint32_t run = 0;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          s_pass_off[ps] = run;
-          run += (carry[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
-        }
-        s_pass_off[8] = run;
+      for (int ps = 0; ps < 8; ++ps) {
+        X.poff[ps] = run;
+        run += (carry[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
       }
-      __syncthreads();
-      const uint32_t sub_entries = bad ? 0u : s_pass_off[8];
-      if ((uint64_t)ent_cur + sub_entries > vp.num_entries) bad = true;
+      const uint32_t sub_entries = bad ? 0u : run;
+      if ((uint64_t)ent_cur + sub_entries > pkt_entries) bad = true;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the entries have landed in s_ent
 
-      // ---- accumulate: a lane owns VQ_GROUP consecutive elements of one partition of one vector ----
-      const uint32_t gpp = (psize + VQ_GROUP - 1) / VQ_GROUP;      // groups per partition
-      const uint32_t body = parts * psize;                         // elements that can receive values: [lim_begin, lim_begin + body)
-      const uint32_t groups = npj * gpp;
-      const uint16_t* esub = ent + ent_cur;
-      for (uint32_t gi = lane; gi < groups; gi += VQ_THREADS) {
-        const uint32_t pj = gi / gpp, w0 = (gi - pj * gpp) * VQ_GROUP;
-        const uint32_t pc = pj / vch, j = pj - pc * vch;
-        const uint32_t cnt_el = min((uint32_t)VQ_GROUP, psize - w0);
-        float acc[VQ_GROUP];
-#pragma unroll
-        for (int k = 0; k < VQ_GROUP; ++k) acc[k] = 0.f;
-        if (!bad && ((vused >> j) & 1u)) {
-          const uint32_t c = cls[(size_t)j * parts + pc];
-          if (c >= r->nclass) {
-            raise_status(status, VSYN_ST_BAD_VQ, p);
-          } else {
-            const uint4 bw = *(const uint4*)&s_books[c * 8];
-            const uint32_t w[4] = {bw.x, bw.y, bw.z, bw.w};
-            uint32_t st4[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) st4[k] = s_start[k * npj + pj];
-            bool bad_entry = false;
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {  // pass order = order of the additions (hpp:711)
-              const int book = (int16_t)(w[ps >> 1] >> (16 * (ps & 1)));
-              if (!__any(book >= 0)) continue;  // wave-uniform: nobody has a codebook in this pass (typical for passes 3..7)
-              if (book < 0) continue;
-              const VqBookLds bk = s_book[book];
-              const uint16_t* e0 = esub + s_pass_off[ps] + ((st4[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu);
-              const float* tab = pool + bk.table_off;  // 32-byte aligned (vq_build_block)
-              const uint32_t dims = bk.dims, nent = bk.entries & 0x00FFFFFFu;
-              const uint32_t sh = (bk.entries >> 24) & 31u;
-              const bool fast = r->type != 0 && (bk.entries >> 31) != 0u && cnt_el == VQ_GROUP;  // 8.6.4, power-of-two vector length
-              float add[VQ_GROUP];
-              if (fast && sh >= 3) {         // one vector covers the group's 8 elements: 8 consecutive components
-                const uint32_t en = e0[w0 >> sh];
-                const bool ok = en < nent;
-                bad_entry |= !ok;
-                const float4* v4 = (const float4*)(tab + (size_t)(ok ? en : 0u) * dims + (w0 & (dims - 1u)));
-                const float4 a = v4[0], b = v4[1];
-                add[0] = a.x; add[1] = a.y; add[2] = a.z; add[3] = a.w;
-                add[4] = b.x; add[5] = b.y; add[6] = b.z; add[7] = b.w;
-                if (!ok) {
-#pragma unroll
-                  for (int k = 0; k < VQ_GROUP; ++k) add[k] = 0.f;
-                }
-              } else if (fast && sh == 2) {  // two vectors of 4
-                const uint32_t i0 = w0 >> 2;
-                const uint32_t en0 = e0[i0], en1 = e0[i0 + 1];
-                const bool ok0 = en0 < nent, ok1 = en1 < nent;
-                bad_entry |= !(ok0 && ok1);
-                const float4 a = *(const float4*)(tab + (size_t)(ok0 ? en0 : 0u) * 4u);
-                const float4 b = *(const float4*)(tab + (size_t)(ok1 ? en1 : 0u) * 4u);
-                add[0] = ok0 ? a.x : 0.f; add[1] = ok0 ? a.y : 0.f; add[2] = ok0 ? a.z : 0.f; add[3] = ok0 ? a.w : 0.f;
-                add[4] = ok1 ? b.x : 0.f; add[5] = ok1 ? b.y : 0.f; add[6] = ok1 ? b.z : 0.f; add[7] = ok1 ? b.w : 0.f;
-              } else if (fast && sh == 1) {  // four vectors of 2
-                const uint32_t i0 = w0 >> 1;
-                uint32_t en[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) en[k] = e0[i0 + k];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const bool ok = en[k] < nent;
-                  bad_entry |= !ok;
-                  const float2 a = *(const float2*)(tab + (size_t)(ok ? en[k] : 0u) * 2u);
-                  add[2 * k] = ok ? a.x : 0.f;
-                  add[2 * k + 1] = ok ? a.y : 0.f;
-                }
-              } else if (fast) {             // eight scalars
-                uint32_t en[VQ_GROUP];
-#pragma unroll
-                for (int k = 0; k < VQ_GROUP; ++k) en[k] = e0[w0 + k];
-#pragma unroll
-                for (int k = 0; k < VQ_GROUP; ++k) {
-                  const bool ok = en[k] < nent;
-                  bad_entry |= !ok;
-                  const float v = tab[ok ? en[k] : 0u];
-                  add[k] = ok ? v : 0.f;
-                }
-              } else {
-                bad_entry |= vq_gather_general(add, r->type, psize, w0, bk.per_part, dims, nent, e0, tab);
-              }
-#pragma unroll
-              for (int k = 0; k < VQ_GROUP; ++k) acc[k] += add[k];
-            }
-            if (bad_entry) raise_status(status, VSYN_ST_BAD_VQ, p);
-          }
-        }
-        // store (de-interleaving format 2: element e of the interleaved vector is bin e / nch of channel e % nch, hpp:690-692)
-        const uint32_t e_first = lim_begin + pc * psize + w0;
-        if (fmt2 && nch == 2 && cnt_el == VQ_GROUP && !(e_first & 1u)) {  // stereo: 4 consecutive bins per channel
-          float* o0 = out + (size_t)chan[0] * n2 + (e_first >> 1);
-          float* o1 = out + (size_t)chan[1] * n2 + (e_first >> 1);
-          if (((uintptr_t)o0 & 15u) == 0 && ((uintptr_t)o1 & 15u) == 0) {
-            *(float4*)o0 = make_float4(acc[0], acc[2], acc[4], acc[6]);
-            *(float4*)o1 = make_float4(acc[1], acc[3], acc[5], acc[7]);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              o0[k] = acc[2 * k];
-              o1[k] = acc[2 * k + 1];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < VQ_GROUP; ++k)
-            if ((uint32_t)k < cnt_el) {
-              const uint32_t e = e_first + k;
-              if (fmt2) out[(size_t)chan[e % nch] * n2 + e / nch] = acc[k];
-              else out[(size_t)chan[j] * n2 + e] = acc[k];
-            }
-        }
+      // ---- accumulate + store ----
+      bool bad_entry;
+      if (ent_lds) bad_entry = vq_accumulate<true>(X, lane, bad, vused, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
+      else bad_entry = vq_accumulate<false>(X, lane, bad, vused, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
+      if (bad_entry) raise_status(status, VSYN_ST_BAD_VQ, p);
+
+      // elements outside the partitions stay zero (hpp:1186-1190): [0, lim_begin) and [lim_begin + parts * psize, len) of every
+      // vector; per channel these are two runs of consecutive bins (format 2: element e is bin e / nch of channel e % nch)
+      const uint32_t tail0 = lim_begin + X.parts * X.psize;
+      for (uint32_t k = 0; k < nch; ++k) {
+        float* o = out + (size_t)s_chan[k] * n2;
+        const uint32_t h1 = fmt2 ? (lim_begin + nch - 1u - k) / nch : lim_begin;  // bins below: b * nch + k < lim_begin
+        const uint32_t t0 = fmt2 ? (tail0 + nch - 1u - k) / nch : tail0;          // bins from: b * nch + k >= tail0
+        for (uint32_t b = lane; b < h1; b += VQ_THREADS) o[b] = 0.f;
+        for (uint32_t b = t0 + lane; b < n2; b += VQ_THREADS) o[b] = 0.f;
       }
-      // elements outside the partitions stay zero (hpp:1186-1190): [0, lim_begin) and [lim_begin + body, len)
-      const uint32_t tail0 = lim_begin + body;
-      for (uint32_t j = 0; j < vch; ++j) {
-        for (uint32_t e = lane; e < lim_begin; e += VQ_THREADS) {
-          if (fmt2) out[(size_t)chan[e % nch] * n2 + e / nch] = 0.f;
-          else out[(size_t)chan[j] * n2 + e] = 0.f;
-        }
-        for (uint32_t e = tail0 + lane; e < len; e += VQ_THREADS) {
-          if (fmt2) out[(size_t)chan[e % nch] * n2 + e / nch] = 0.f;
-          else out[(size_t)chan[j] * n2 + e] = 0.f;
-        }
-      }
-      cls_cur += npj;
+      cls_cur += X.npj;
       ent_cur += sub_entries;
     }
-    if (lane == 0 && (bad || ent_cur != vp.num_entries)) raise_status(status, VSYN_ST_BAD_VQ, p);  // count must match the classifications
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a packet without submaps: the entry loads must not outlive s_ent's reuse)
+    if (lane == 0 && (bad || ent_cur != pkt_entries)) raise_status(status, VSYN_ST_BAD_VQ, p);  // count must match the classifications
   }
 }
 #endif  // __HIPCC__
@@ -363,7 +465,7 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
   if (vq->num_residues == 0 || vq->num_residues > VSYN_MAX_TABLES || !vq->residues) return "vq setup: residue count out of range";
   if (!vq->mappings) return "vq setup: mappings is NULL";
   std::vector<VqBook> books(vq->num_codebooks);
-  std::vector<float> pool;
+  std::vector<float> pool(8, 0.f);  // a zero vector first: what an out-of-range entry number reads instead of a table row
   for (uint32_t i = 0; i < vq->num_codebooks; ++i) {
     const vsyn_codebook& b = vq->codebooks[i];
     books[i].dims = b.dimensions;
@@ -393,6 +495,7 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
     d.psize = r.partition_size;
     d.nclass = r.num_classifications;
     d.classwords = r.classwords;
+    d.pass_mask = 0;
     for (uint32_t k = 0; k < 64 * 8; ++k) d.books[k] = -1;
     for (uint32_t k = 0; k < r.num_classifications * 8; ++k) {
       const int b = r.books[k];
@@ -401,11 +504,13 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
       if (books[b].table_off == 0xFFFFFFFFu) return "vq setup: residue uses codebook " + std::to_string(b) + " which has no value table";
       if (r.partition_size % books[b].dims) return "vq setup: vector length of codebook " + std::to_string(b) + " does not divide the partition size";
       d.books[k] = (int16_t)b;
+      d.pass_mask |= 1u << (k & 7u);
     }
   }
   std::vector<VqMap> maps(vq->num_mappings);
   const uint32_t n2max = H.bs[1] / 2u;
-  uint32_t max_slots = 64;
+  uint32_t max_slots = 64, max_classes = 1;
+  for (const VqResidue& r : residues) max_classes = std::max(max_classes, r.nclass);
   for (uint32_t m = 0; m < vq->num_mappings; ++m) {
     const vsyn_vq_mapping& s = vq->mappings[m];
     VqMap& d = maps[m];
@@ -418,9 +523,14 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
     }
     for (uint32_t k = 0; k < s.num_submaps; ++k) {
       if (s.submap_residue[k] >= vq->num_residues) return "vq setup: submap names a residue that does not exist";
-      d.submap_residue[k] = s.submap_residue[k];
+      d.sub_rid[k] = s.submap_residue[k];
       uint32_t nch = 0;
-      for (uint32_t ch = 0; ch < H.channels; ++ch) nch += s.mux[ch] == k;
+      for (uint32_t ch = 0; ch < H.channels; ++ch)
+        if (s.mux[ch] == k) {
+          if (nch < 4) d.sub_chan4[k] |= ch << (8 * nch);
+          ++nch;
+        }
+      d.sub_nch[k] = nch;
       if (!nch) continue;
       const VqResidue& r = residues[s.submap_residue[k]];
       const uint32_t len = r.type == 2 ? nch * n2max : n2max, vch = r.type == 2 ? 1u : nch;
@@ -436,6 +546,7 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
   vh.num_residues = vq->num_residues;
   vh.num_maps = vq->num_mappings;
   vh.max_slots = max_slots;
+  vh.max_classes = max_classes;
   auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   size_t off = align16(sizeof(VqHeader));
   vh.off_books = (uint32_t)off;
