@@ -6,23 +6,31 @@
 // pass (hpp:737-753), then de-interleave format 2 (hpp:687-693) — and writes "after_residue" in the packing the
 // synthesis kernels read.
 //
-// One wavefront per packet (a fixed grid of single-wave workgroups walks the packets; the staged tables survive from packet
-// to packet while the residue in use stays the same), two phases per submap vector:
+// One wavefront per packet (as many single-wave workgroups as are resident at once walk the packets; the per-residue tables a
+// wave stages in LDS survive from packet to packet while the residue in use stays the same). Per packet:
+//   descriptors PktInfo, vsyn_vq_packet, the mapping's submap records and the residue header are wave-uniform: scalar loads.
+//   entries     the packet's entry numbers (<= VQ_ENT_CAP) go to LDS with direct-to-LDS loads (global_load_lds_dwordx4, no
+//               registers), issued first and waited for only before the accumulate phase.
 //   scan        how many entries each (pass, partition, vector) slot consumes, and the exclusive scan of that in decode order
 //               -> where each slot's first entry sits.  Lane = one (partition, vector) pair with its 8 passes; two passes share
-//               a 32-bit word, so four DPP scans give the eight per-pass prefix sums.
+//               a 32-bit word, so four DPP scans give the eight per-pass prefix sums.  The classification bytes are read once,
+//               here, and kept in LDS.
 //   accumulate  every ELEMENT belongs to exactly one partition and receives at most one value per pass, so a lane that owns
 //               VQ_GROUP consecutive elements of a partition adds their up-to-8 contributions in pass order in registers —
-//               the same sequence of f32 additions as the reference —, then stores each element once (zero outside the
-//               partitions, format 2 de-interleaved, 16-byte stores).  No atomics, no zero-fill pass.  Vector lengths 1, 2, 4
-//               and 8+ (powers of two) read their entries and value vectors with whole-vector loads; a pass nobody in the wave
-//               has a book for is skipped wave-uniformly; format 0, odd lengths and partition tails go through one out-of-line
-//               per-element routine.
-// Measured alternatives (bench.py --workload config3_vq, 65 536 stereo long packets, kernel time): this design 0.54 ms;
+//               the same sequence of f32 additions as the reference —, then stores each element once (format 2 de-interleaved,
+//               16-byte stores).  No atomics.  Only passes in which the residue has a codebook at all are visited (a scalar loop
+//               over the set bits); vector lengths 1, 2, 4 and 8+ (powers of two) read their entries from LDS and their value
+//               vectors with whole-vector loads; an out-of-range entry number reads the zero vector that heads the pool (and
+//               raises the status); format 0, odd lengths and partition tails go through one out-of-line per-element routine.
+//   zero fill   the bins outside the partitions are two runs of consecutive bins per channel.
+// A single wave needs no barriers: its LDS operations execute in order.
+// Measured (bench.py --workload config3_vq, 65 536 stereo long packets, kernel time): this design 0.29 ms — VALU issue is
+// what binds it now (1376 VALU wave-instructions per packet at 45 % lane utilisation: the lanes of a wave hold different
+// classes, so every vector-length variant of a pass runs).  Its predecessor (entries and classifications read from global
+// memory inside the accumulate loop, per-pass LDS book records, zero fill element by element) 0.48 ms; earlier alternatives:
 // workgroup of 128/256 threads per packet 0.67-0.88 ms; separate scan + accumulate kernels (thread = element group, no
-// per-packet loop) 0.69 ms; thread = one entry of a pass with f32 accumulators in LDS and the entry stream staged in LDS
-// 0.69-0.77 ms (1.0 ms with 4 entries per thread in flight).  All of them are bound by the chain of dependent phases of one
-// packet times the number of packets a CU keeps in flight, not by bytes or instructions.
+// per-packet loop) 0.69 ms; thread = one entry of a pass with f32 accumulators in LDS 0.69-0.77 ms; forcing 8 waves/SIMD
+// (64 VGPRs, spills) 0.53 ms.
 #pragma once
 #include "vsyn_device.h"
 
@@ -100,12 +108,31 @@ __device__ __forceinline__ uint32_t vq_wave_scan(uint32_t v) {
   return v;
 }
 
+// The general element -> (vector, component) mapping, out of line (cold): format 0 (8.6.3, hpp:738-746: element w <- vector
+// w % step, component w / step), vector lengths that are not a power of two, partition tails. Returns the float index of the
+// element's value in the pool: 0 (the zero vector) beyond the partition, 0xFFFFFFFF for an entry number out of range.
+__device__ __noinline__ uint32_t vq_general_index(uint32_t type, uint32_t psize, uint32_t ww, uint32_t step, uint32_t nent1, uint32_t tab,
+                                                  uint32_t e0, bool ent_lds, const uint16_t* s_ent, const uint16_t* __restrict__ eg) {
+  if (ww >= psize) return 0u;
+  const uint32_t dims = psize / step;
+  uint32_t ei, li;
+  if (type == 0u) {
+    li = ww / step;
+    ei = ww - li * step;
+  } else {
+    ei = ww / dims;
+    li = ww - ei * dims;
+  }
+  const uint32_t en = ent_lds ? (uint32_t)s_ent[e0 + ei] : (uint32_t)eg[e0 + ei];
+  return en <= nent1 ? tab + en * dims + li : 0xFFFFFFFFu;
+}
+
 // Everything one submap vector needs in the accumulate phase (wave-uniform)
 struct VqSubCtx {
   uint32_t type, psize, vch, nch, npj, parts, lim_begin, len, n2, gpp, pass_mask;
   uint32_t chan0, chan1;
   uint32_t ent_base;        // first entry of the submap relative to the packet's first entry
-  uint32_t poff[8];         // first entry of each pass relative to ent_base
+  uint32_t poff_lanes;      // lane k < 8: first entry of pass k relative to ent_base (read with readlane)
   uint32_t ent_shift;       // ENT_LDS: index of the packet's first entry inside s_ent
 };
 
@@ -137,12 +164,14 @@ __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t 
     if (!bad && c != 0xFFu) {
       const uint32_t vm = s_vm[c];
       const vq_u32x4 st4 = s_start[pj];
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {  // pass order = order of the additions (hpp:711)
-        if (!((X.pass_mask >> ps) & 1u)) continue;  // wave-uniform: no class of this residue has a codebook here (typical for passes 3..7)
+      // pass order = order of the additions (hpp:711); only passes in which some class of this residue has a codebook (wave-uniform)
+#pragma unroll 1
+      for (uint32_t pm = X.pass_mask; pm; pm &= pm - 1u) {
+        const uint32_t ps = (uint32_t)__builtin_ctz(pm);
         if (!((vm >> ps) & 1u)) continue;
         const VqCp cp = s_cp[c * 8u + ps];
-        const uint32_t e0 = X.ent_base + X.poff[ps] + ((st4[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu);
+        const uint32_t stw = ps < 4u ? (ps < 2u ? st4[0] : st4[1]) : (ps < 6u ? st4[2] : st4[3]);
+        const uint32_t e0 = X.ent_base + (uint32_t)__builtin_amdgcn_readlane((int)X.poff_lanes, (int)ps) + ((stw >> (16u * (ps & 1u))) & 0xFFFFu);
         const uint32_t nent1 = cp.inf & 0xFFFFu, sh = (cp.inf >> 16) & 15u;
         float add[VQ_GROUP];
         if ((cp.inf & VQ_CP_FAST) && cnt_el == VQ_GROUP) {
@@ -189,28 +218,12 @@ __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t 
             }
           }
         } else {
-          // The general element -> (vector, component) mapping: format 0 (8.6.3, hpp:738-746: element w <- vector w % step,
-          // component w / step), vector lengths that are not a power of two, partition tails.
           const uint32_t step = s_pp[c * 8u + ps];  // vectors per partition
-          const uint32_t dims = X.psize / step;
 #pragma unroll
           for (int k = 0; k < VQ_GROUP; ++k) {
-            const uint32_t ww = w0 + k;
-            uint32_t idx = 0;
-            if (ww < X.psize) {
-              uint32_t ei, li;
-              if (X.type == 0u) {
-                li = ww / step;
-                ei = ww - li * step;
-              } else {
-                ei = ww / dims;
-                li = ww - ei * dims;
-              }
-              const uint32_t en = entry(e0 + ei);
-              if (en <= nent1) idx = cp.tab + en * dims + li;
-              else bad_entry = true;
-            }
-            add[k] = pool[idx];
+            const uint32_t idx = vq_general_index(X.type, X.psize, w0 + k, step, nent1, cp.tab, e0, ENT_LDS, s_ent + X.ent_shift, eg);
+            bad_entry |= idx == 0xFFFFFFFFu;
+            add[k] = pool[idx == 0xFFFFFFFFu ? 0u : idx];
           }
         }
 #pragma unroll
@@ -417,9 +430,10 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
         if (lane == 0) raise_status(status, VSYN_ST_BAD_VQ, p);
       }
       uint32_t run = 0;
+      X.poff_lanes = 0;
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
-        X.poff[ps] = run;
+        if (lane == (uint32_t)ps) X.poff_lanes = run;
         run += (carry[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
       }
       const uint32_t sub_entries = bad ? 0u : run;
