@@ -137,6 +137,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // (Explicit LDS address space: a volatile access through a generic pointer compiles to flat_load/flat_store, whose wait
 // also drains the vector-memory queue and with it the look-ahead residue loads.)
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) float lds_f32;
 __device__ __forceinline__ void pair_post(lds_u32* flag, uint32_t v) {
   asm volatile("" ::: "memory");
   *(volatile lds_u32*)flag = v;
@@ -180,7 +181,7 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 static_assert(sizeof(PktInfo) == 32, "PktInfo is fetched as one s_load_dwordx8");
 struct PktScalars {
   uint64_t res_off;
-  uint32_t out_pos, emit, used, own, widx, mapping;
+  uint32_t out_pos, emit, used, own, widx, mapping, lng, bad;
 };
 __device__ __forceinline__ PktScalars pkt_fields(const u32x8 r) {
   PktScalars k;
@@ -191,6 +192,8 @@ __device__ __forceinline__ PktScalars pkt_fields(const u32x8 r) {
   k.own = r[5];
   k.widx = r[6] >> 24;
   k.mapping = r[7] & 0xFFu;
+  k.lng = (r[6] >> 16) & 0xFFu;
+  k.bad = (r[7] >> 8) & 0xFFu;
   return k;
 }
 __device__ __forceinline__ PktScalars pkt_load(const PktInfo* p) {  // p wave-uniform
@@ -202,11 +205,27 @@ __device__ __forceinline__ PktScalars pkt_load(const PktInfo* p) {  // p wave-un
 // ROLE: 0 channel c is not coupled; 1 c is the magnitude channel of the (single) coupling step, `pc` its angle
 // partner; 2 c is the angle channel, `pc` the magnitude partner. A coupled wave loads both channels' residue and
 // keeps only its own side of hpp:1219-1240 (5 VALU per bin instead of 7 for both).
-template <int ROLE>
+//
+// MIXED = false: every block of the run (halo included) is long and there is no carry-in — the steady state, nothing below
+// about short blocks is compiled in.  MIXED = true: short blocks (n = 256: one complex point per lane, FFT-64 as six
+// cross-lane radix-2 stages), window switches and a carry-in from an earlier submit.  The overlap term of a block comes
+//   K_REG     from registers when the previous block had the same size (P[8] / Ps, unwindowed, same lane layout),
+//   K_LDS     from the wave's 128-float carry image when the size changed: a long block followed by a short one writes the
+//             448 frames that only it contributes to straight into the next chunk and its 128 windowed overlap frames into the
+//             image; a short block followed by a long one writes its 128 windowed right-half samples there; the next block
+//             reads the image in its own lane layout.  Every chunk sample is stored exactly once (no read-modify-write
+//             through memory, no fences),
+//   K_CARRY   from the stream's carry buffer (windowed right half in natural order) for a long block after a long carry-in.
+// `buf = 0; buf += prev*w; buf += cur*w` (hpp:1008-1017) with the same two roundings in every case.
+enum { K_REG = 0, K_LDS = 1, K_CARRY = 2 };
+__device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
+
+template <int ROLE, bool MIXED>
 __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb, float4* __restrict__ seg,
-                                          lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane0, const uint32_t g, const vsyn_segment sg, const SegInfo si,
-                                          const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c, const uint32_t pc) {
-  constexpr uint32_t M = 1024;
+                                          lds_f32* cbuf, lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane0, const uint32_t g,
+                                          const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c,
+                                          const uint32_t pc) {
+  constexpr uint32_t ML = 1024;
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
   const uint32_t num = sg.num_packets;
@@ -215,6 +234,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 #pragma unroll
   for (int k = 0; k < 8; ++k) P[k] = 0.f;
   uint32_t prev_next_long = 1;
+  float Ps = 0.f;               // MIXED: unwindowed right-half value of the previous SHORT block at this lane's point
+  uint32_t prev_kind = K_REG;   // MIXED: where the overlap term comes from (wave-uniform)
+  uint32_t prev_half = 0;       // MIXED: samples the previous block contributes to the current chunk's frame count: 1024 / 128 / 0
+  float* const plane = A.pcm + ((size_t)g * C + c) * A.plane_stride;
+  const float* cin = nullptr;   // MIXED: carry-in of this (stream, channel)
 
   // lane constants of the floor in use (reloaded only when the floor changes, wave-uniform)
   const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg;  // this wave's entry table inside LDS (entries are 8 bytes)
@@ -237,11 +261,30 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   const uint32_t q0 = qa ? qa - 1 : 0;
   const PktInfo* const ip = A.info + __builtin_amdgcn_readfirstlane(sg.first_packet);
   PktScalars pi = pkt_load(ip + q0);
-  float2 raw[8];  // own channel's residue, requested one packet ahead
-  {
-    const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M) + lane0;
+  float2 raw[8];  // own channel's residue; steady runs request it one packet ahead (mixed runs have no registers to spare for that)
+  if (!MIXED) {
+    const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * ML) + lane0;
 #pragma unroll
     for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
+  }
+  if (MIXED && qa == 0 && si.has_carry && !pi.bad) {
+    // the previous submit left this stream's windowed right half in natural order (carry_n / 2 samples)
+    const size_t carry_half = (size_t)H->max_streams * C * ML;
+    cin = A.carry + si.parity_in * carry_half + ((size_t)sg.stream * C + c) * ML;
+    const bool carry_long = si.carry_n == 2u * ML;
+    prev_half = si.carry_n / 2u;
+    if (carry_long && pi.lng) {
+      prev_kind = K_CARRY;
+    } else {
+      // a size change (or two short blocks): the 128 overlap frames go through the carry image; a long carry before a
+      // short block also owns the first 448 frames of the chunk outright
+      const uint32_t base = carry_long ? 448u : 0u;
+      if (carry_long)
+        for (uint32_t i = lane0; i < min(448u, pi.emit); i += 64) plane[pi.out_pos + i] = cin[i];
+      cbuf[lane0] = cin[base + lane0];
+      cbuf[lane0 + 64u] = cin[base + lane0 + 64u];
+      prev_kind = K_LDS;
+    }
   }
   uint32_t lane_v = lane0;
   // The two waves of a coupled channel pair (adjacent waves, same run, same packets) each load ONLY their own channel
@@ -259,6 +302,21 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     const uint32_t p = sg.first_packet + q;
     const bool halo = q < qa, has_next = q + 1 < qb;
     const PktScalars pin = pkt_load(ip + (has_next ? q + 1 : q));  // one packet ahead
+    const bool lng = !MIXED || pi.lng != 0u;
+    const bool nlng = !MIXED || pin.lng != 0u;
+    const uint32_t M = lng ? ML : 128u;
+    if (MIXED && pi.bad) {
+      // invalid mode number: the layout kernel flagged it; nothing to synthesise (outputs after it are unspecified). Both
+      // waves of a pair skip it, so the hand-off counters stay in step.
+#pragma unroll
+      for (int k = 0; k < 8; ++k) P[k] = 0.f;
+      Ps = 0.f;
+      prev_kind = K_REG;
+      prev_half = 0;
+      vrow_ok = false;
+      pi = pin;
+      continue;
+    }
     if (pi.mapping != cur_map) {  // wave-uniform, rare
       cur_map = pi.mapping;
       map_floor = __builtin_amdgcn_readfirstlane((uint32_t)maps[cur_map].chfloor[c]);
@@ -267,29 +325,42 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     // ---- residue: bins (2k, 2k+1), k = lane + 64 t (requested one packet ahead, see below); inverse coupling keeps
     //      this wave's side only (hpp:1213-1241) ----------------------------------------------------------------
     float2 r[8];
-    if (ROLE != 0) {
+    // L = rows of the block: all 8 (long) or the first (short); called with a literal so that each copy is straight-line code
+    auto residue_rows = [&](const bool L) {
+      if (MIXED) {
+        const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * (L ? ML : 128u)) + lane;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
-      pair_post(&my_flags[0], it + 1);
-      pair_wait(&partner_flags[0], it + 1);  // both channels of the pair are in LDS
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (ROLE == 0) {
-        r[t] = raw[t];
-      } else {
-        const float2 oth = pxb[t * 64 + lane];
-        r[t] = ROLE == 1 ? f2(couple_mag(raw[t].x, oth.x), couple_mag(raw[t].y, oth.y))
-                         : f2(couple_ang(oth.x, raw[t].x), couple_ang(oth.y, raw[t].y));
+        for (int t = 0; t < 8; ++t)
+          if (t == 0 || L) raw[t] = src[64 * t];
       }
-    }
+      if (ROLE != 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t == 0 || L) xb[t * 64 + lane] = raw[t];
+        pair_post(&my_flags[0], it + 1);
+        pair_wait(&partner_flags[0], it + 1);  // both channels of the pair are in LDS
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t != 0 && !L) continue;
+        if (ROLE == 0) {
+          r[t] = raw[t];
+        } else {
+          const float2 oth = pxb[t * 64 + lane];
+          r[t] = ROLE == 1 ? f2(couple_mag(raw[t].x, oth.x), couple_mag(raw[t].y, oth.y))
+                           : f2(couple_ang(oth.x, raw[t].x), couple_ang(oth.y, raw[t].y));
+        }
+      }
+    };
+    if (lng) residue_rows(true);
+    else residue_rows(false);
     if (ROLE != 0) pair_post(&my_flags[1], it + 1);
     // `raw` is dead: request packet q+1 now, so that its 4 KiB stay in flight behind this packet's floor product, FFT and
     // overlap (memory-level parallelism bounded this kernel, not occupancy). Unconditional on purpose: on a run's last
     // packet the current block is re-read (cache-resident, 1/R of the loads) — a `has_next` guard lets the compiler fold
     // these loads back into the loop header.
-    {
-      const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * M) + lane;  // one 64-bit add, immediate offsets
+    if (!MIXED) {
+      const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * ML) + lane;  // one 64-bit add, immediate offsets
 #pragma unroll
       for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
     }
@@ -309,7 +380,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       if (cur_floor != (int)f) {  // wave-uniform, changes only when the mapping changes
         const FloorConst* fc = floors + f;
         posts = __builtin_amdgcn_readfirstlane(fc->posts);
-        const uint8_t* bs = A.binseg + (size_t)f * M;
+        const uint8_t* bs = A.binseg + (size_t)f * ML;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));  // intervals of bins 2k, 2k+1 (k = lane + 64 t)
@@ -355,324 +426,195 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     // (a channel without a curve was given a constant x1.0 / x0.0 entry above: no branch here)
     // Two dependent LDS look-ups per bin (segment entry, then inverse-dB value). Done four bins at a time so that a
     // group's look-ups are in flight together: one exposed LDS round trip per group instead of one per bin.
-    const float xf0 = (float)(2u * lane);
-    float fl[16];
+    auto floor_product = [&](const bool L) {
+      const float xf0 = (float)(2u * lane);
+      float fl[16];
 #pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
-      float2 sgm[4];
+      for (int grp = 0; grp < 4; ++grp) {
+        if (grp != 0 && !L) continue;  // a short block: bins 2 lane, 2 lane + 1 only (the others of group 0 are computed and unused)
+        float2 sgm[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int b = 4 * grp + i;
-        const uint32_t addr = (b & 1) ? (bseg[b >> 1] >> 16) : (bseg[b >> 1] & 0xFFFFu);  // one VALU op per bin
-        typedef float lds_vf2 __attribute__((ext_vector_type(2)));
-        const lds_vf2 ev = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)addr;
-        sgm[i] = f2(ev.x, ev.y);
+        for (int i = 0; i < 4; ++i) {
+          const int b = 4 * grp + i;
+          const uint32_t addr = (b & 1) ? (bseg[b >> 1] >> 16) : (bseg[b >> 1] & 0xFFFFu);  // one VALU op per bin
+          typedef float lds_vf2 __attribute__((ext_vector_type(2)));
+          const lds_vf2 ev = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)addr;
+          sgm[i] = f2(ev.x, ev.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = 4 * grp + i;
+          // the argument is positive (it exceeds a table index >= 0), so the conversion's truncation is the floor
+          fl[b] = T.invdb[(uint32_t)__builtin_fmaf(xf0 + (float)(128 * (b >> 1) + (b & 1)), sgm[i].x, sgm[i].y)];
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int b = 4 * grp + i;
-        // the argument is positive (it exceeds a table index >= 0), so the conversion's truncation is the floor
-        fl[b] = T.invdb[(uint32_t)__builtin_fmaf(xf0 + (float)(128 * (b >> 1) + (b & 1)), sgm[i].x, sgm[i].y)];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) r[t] = f2(r[t].x * fl[2 * t], r[t].y * fl[2 * t + 1]);
+      for (int t = 0; t < 8; ++t)
+        if (t == 0 || L) r[t] = f2(r[t].x * fl[2 * t], r[t].y * fl[2 * t + 1]);
+    };
 
-    // ---- IMDCT: mirror exchange, pre-rotation, FFT-512, post-rotation -------------------------------------
-    float2 z[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const float im = __shfl(r[7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
-      z[t] = cmulf(f2(r[t].x, im), T.pre[t][lane]);
-    }
-    if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT may reuse it
-#ifdef VSYN_EXP_SETPRIO
-    __builtin_amdgcn_s_setprio(VSYN_EXP_SETPRIO);
-#endif
-    fft512_wave(z, xb, &T, lane);
-#ifdef VSYN_EXP_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-    for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post[k][lane]);
-
-    // ---- window + overlap-add + PCM store (hpp:1008-1059) --------------------------------------------------
-    // point m = kappa + 64k gives samples s and 1023-s of this packet's output:
-    //   out[s]      = fl(P*wr(s))      + fl( cc*wl(s))        cc =  u_cur[512+s]
-    //   out[1023-s] = fl(P*wr(1023-s)) + fl(-cc*wl(1023-s))   P  = -u_prev[511-s]
-    // Handled as four point pairs (k, 7-k): each pair yields the contiguous samples (s, s+1) and (1022-s, 1023-s)
-    // after one exchange with the mirror lane. Computed for halo / first packets too (emit == 0): only the stores are
-    // guarded. P is zero until the run has seen a block; 0*w + x == x exactly as in `buf = 0; buf += x`.
     const uint32_t emit = halo ? 0u : pi.emit;
-    const float (*TL)[8][64] = T.win[pi.widx & 1u];    // this block's left-half window
-    const float (*TR)[8][64] = T.win[prev_next_long];  // previous block's right-half window, mirrored
+    float* out = plane + pi.out_pos;
     const uint32_t cur_next_long = (pi.widx >> 1) & 1u;
-    float* out = A.pcm + ((size_t)g * C + c) * A.plane_stride + pi.out_pos;
-    const bool fast_store = emit == M && (((uintptr_t)out & 7u) == 0);
-    float oh_s[4], oh_m[4], n_s[4], n_m[4];
-    // window values of this lane's 8 points: left half of this block and mirrored right half of the previous one. Between
-    // two long blocks that is the same table (wave-uniform test): read it once.
-    float wl0[8], wl1[8], wr0[8], wr1[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      wl0[k] = TL[0][k][lane];
-      wl1[k] = TL[1][k][lane];
-    }
-    if (TR == TL) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        wr0[k] = wl0[k];
-        wr1[k] = wl1[k];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        wr0[k] = TR[0][k][lane];
-        wr1[k] = TR[1][k][lane];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kh = 4 + j, kl = 3 - j;  // kh: even sample s = 2m-512 (own), kl: odd sample 511-2m (goes to the mirror lane)
-      const float cch = z[kh].x, ccl = -z[kl].y;
-      oh_s[j] = P[kh] * wr1[kh] + cch * wl0[kh];
-      oh_m[j] = P[kh] * wr0[kh] + (-cch) * wl1[kh];
-      const float ol_s = P[kl] * wr1[kl] + ccl * wl0[kl];
-      const float ol_m = P[kl] * wr0[kl] + (-ccl) * wl1[kl];
-      P[kh] = z[kh].y;
-      P[kl] = -z[kl].x;
-      // partner point 511 - m of (this lane, kh) is (mirror lane, slot kl): it yields samples s+1 and 1022-s
-      n_s[j] = __shfl(ol_s, 63 - (int)lane);
-      n_m[j] = __shfl(ol_m, 63 - (int)lane);
-    }
-    // sample s = 2*kappa + 128*j of (lane, kh = 4 + j): two lane pointers, every store at an immediate offset
-    if (fast_store) {
-      float* up = out + 2u * kappa;            // samples s, s+1
-      float* dn = out + 1022u - 2u * kappa;    // samples 1022-s, 1023-s
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *(float2*)(up + 128 * j) = f2(oh_s[j], n_s[j]);
-        *(float2*)(dn - 128 * j) = f2(n_m[j], oh_m[j]);
-      }
-    } else if (emit) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t s = 2u * kappa + 128u * j;
-        if (s < emit) out[s] = oh_s[j];
-        if (s + 1u < emit) out[s + 1u] = n_s[j];
-        if (1022u - s < emit) out[1022u - s] = n_m[j];
-        if (1023u - s < emit) out[1023u - s] = oh_m[j];
-      }
-    }
-    if (q == num - 1) {  // stream carry for the next submit: windowed right half, natural order
-      const size_t carry_half = (size_t)H->max_streams * C * M;
-      float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * M;
-      const float (*TN)[8][64] = T.win[cur_next_long];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t m = kappa + 64u * k;
-        const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
-        cout[s] = P[k] * TN[1][k][lane];
-        cout[1023u - s] = P[k] * TN[0][k][lane];
-      }
-    }
-    if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
-    prev_next_long = cur_next_long;
-    pi = pin;
-  }
-}
-
-// ================================================================================================
-// Mixed-block runs (short and long blocks, window switches, carry-in from an earlier submit).
-// Same decomposition — one wavefront per (run, channel), channel pairs sharing their input through LDS — but the
-// overlap-add goes through the output buffer itself instead of registers, because consecutive blocks of different size
-// live in different lane layouts: block q stores its windowed right half into the chunk of block q+1 (or into the
-// stream's carry buffer after the last block), and block q+1, in the same wave, adds its windowed left half on top
-// (`buf = 0; buf += prev*w; buf += cur*w`, hpp:1008-1017, with the same two roundings). Short blocks (n = 256) are one
-// complex point per lane: FFT-64 as six cross-lane radix-2 stages.
-// ================================================================================================
-__device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
-__device__ __forceinline__ bool spk_mode_invalid(const ConstHeader* H, uint32_t mode) { return mode >= H->num_modes; }
-
-// floor-1 segment table of one (packet, channel) into seg[] — same construction as in fused_run
-__device__ __forceinline__ bool build_segment_table(const FusedArgs& A, float4* __restrict__ seg, uint32_t lane, const PktInfo& pi,
-                                                    const MapConst* mc, uint32_t c, uint32_t p, uint32_t C, uint32_t ys_stride,
-                                                    uint32_t& sidx_out, uint32_t& floor_id) {
-  if (!((pi.own >> c) & 1u)) {
-    float4 e;
-    e.x = 0.f;
-    e.y = 0.f;
-    e.z = 0.f;
-    e.w = ((pi.used >> c) & 1u) ? 256.f : 255.f;
-    seg[lane] = e;
-    floor_id = 0xFFFFFFFFu;
-    sidx_out = 0;
-    return false;
-  }
-  const uint32_t f = mc->chfloor[c];
-  const FloorConst* fc = floor_of(A.cb, f);
-  const bool in = lane < fc->posts;
-  const uint32_t sidx = in ? fc->sorted_idx[lane] : 0u, xsl = in ? fc->xs_sorted[lane] : 0u;
-  uint32_t v = (A.fy + ((size_t)p * C + c) * ys_stride)[sidx];
-  if (!in) v = 0;
-  const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
-  const uint64_t below = mask & ((2ull << lane) - 1ull);
-  const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
-  const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
-  const bool has_hi = above != 0ull;
-  const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
-  const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
-  const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
-  const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
-  const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
-  const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
-  const float inv = has_hi ? 1.0f / (x1 - x0) : 0.f;
-  const float ady = fabsf(y1 - y0);
-  float4 e;
-  e.x = ady * inv;
-  e.y = __builtin_fmaf(-ady, x0, 0.5f) * inv;
-  e.z = y1 >= y0 ? 1.f : -1.f;
-  e.w = y0;
-  seg[lane] = e;
-  floor_id = f;
-  sidx_out = sidx;
-  return (v & 0x7FFFu) > 255u;  // hpp:587
-}
-
-__device__ __forceinline__ float floor_at(const float4* __restrict__ seg, const FusedLdsImage& T, const uint8_t* __restrict__ binseg_row, uint32_t x) {
-  const float4 sgm = seg[binseg_row[x]];
-  const float qf = floorf(__builtin_fmaf((float)x, sgm.x, sgm.y));
-  return T.invdb[(uint32_t)__builtin_fmaf(qf, sgm.z, sgm.w)];
-}
-
-template <int ROLE>
-__device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb,
-                                                float4* __restrict__ seg, lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane,
-                                                const uint32_t g, const vsyn_segment sg,
-                                                const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c,
-                                                const uint32_t pc) {
-  const uint8_t* __restrict__ cb = A.cb;
-  const ConstHeader* H = hdr_of(cb);
-  const uint32_t num = sg.num_packets, half1 = H->bs[1] / 2;
-  const uint32_t kappa = ((lane & 7u) << 3) | (lane >> 3), mirror = 63u - lane;
-  float* const plane = A.pcm + ((size_t)g * C + c) * A.plane_stride;
-  const size_t carry_half = (size_t)H->max_streams * C * half1;
-  float* const carry_out = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * half1;
-  const uint32_t q0 = qa ? qa - 1 : 0;
-
-  if (qa == 0 && si.has_carry) {
-    // the previous submit left this stream's windowed right half in natural order: it is the "prev" term of chunk 0
-    const PktInfo p0 = A.info[sg.first_packet];
-    const float* cin = A.carry + si.parity_in * carry_half + ((size_t)sg.stream * C + c) * half1;
-    const uint32_t cnt = min(p0.emit, si.carry_n / 2u);
-    for (uint32_t i = lane; i < cnt; i += 64) plane[p0.out_pos + i] = cin[i];
-  }
-  uint32_t prev_half = (qa == 0) ? (si.has_carry ? si.carry_n / 2u : 0u) : 0u;  // samples the previous block put into this chunk
-
-  // (pairwise hand-off with the partner channel's wave as in fused_run: my_flags[0] "my image holds packet #n's residue",
-  // my_flags[1] "I have read yours"; both waves of a pair walk the same packets and skip the same ones)
-  for (uint32_t it = 0; q0 + it < qb; ++it) {
-    const uint32_t q = q0 + it;
-    const uint32_t p = sg.first_packet + q;
-    const PktInfo pi = A.info[p];
-    const bool halo = q < qa, last_of_segment = q + 1 == num;
-    const PktInfo pin = A.info[last_of_segment ? p : p + 1];
-    if (spk_mode_invalid(H, A.packets[p].mode)) {
-      // invalid mode number: the layout kernel flagged it; nothing to synthesise (outputs after it are unspecified)
-      prev_half = 0;
-      continue;
-    }
-    const MapConst* mc = map_of(cb, pi.mapping);
-    const bool lng = pi.lng != 0;
-    const uint32_t M = pi.n / 2u;
-    // make the previous block's right-half stores (any lane) visible to this block's loads of the same chunk
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-    // ---- residue + coupling (pair shares its input through LDS, as in fused_run) -------------------------------
-    float2 r[8];
-    {
-      const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * M);
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t == 0 || lng) r[t] = src[lane + 64 * t];
-    }
-    if (ROLE != 0) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t == 0 || lng) xb[t * 64 + lane] = r[t];
-      pair_post(&my_flags[0], it + 1);
-      pair_wait(&partner_flags[0], it + 1);
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t == 0 || lng) {
-          const float2 oth = pxb[t * 64 + lane];
-          r[t] = ROLE == 1 ? f2(couple_mag(r[t].x, oth.x), couple_mag(r[t].y, oth.y)) : f2(couple_ang(oth.x, r[t].x), couple_ang(oth.y, r[t].y));
-        }
-      pair_post(&my_flags[1], it + 1);
-    }
-
-    // ---- floor curve + product ---------------------------------------------------------------------------------
-    uint32_t sidx_unused, floor_id;
-    const bool floor_bad = build_segment_table(A, seg, lane, pi, mc, c, p, C, H->ys_stride, sidx_unused, floor_id);
-    {
-      // bin -> sorted-post interval: row of this floor (any row works for the constant entry of a curve-less channel)
-      const uint8_t* brow = A.binseg + (size_t)(floor_id == 0xFFFFFFFFu ? 0u : floor_id) * half1;
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t == 0 || lng) {
-          const uint32_t x = 2u * (lane + 64u * t);
-          const uint32_t b0 = floor_id == 0xFFFFFFFFu ? 0u : x, b1 = floor_id == 0xFFFFFFFFu ? 0u : x + 1u;
-          const float4 s0 = seg[floor_id == 0xFFFFFFFFu ? lane : brow[b0]], s1 = seg[floor_id == 0xFFFFFFFFu ? lane : brow[b1]];
-          const float q0f = floorf(__builtin_fmaf((float)x, s0.x, s0.y)), q1f = floorf(__builtin_fmaf((float)(x + 1u), s1.x, s1.y));
-          r[t] = f2(r[t].x * T.invdb[(uint32_t)__builtin_fmaf(q0f, s0.z, s0.w)], r[t].y * T.invdb[(uint32_t)__builtin_fmaf(q1f, s1.z, s1.w)]);
-        }
-    }
-    if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
-
-    // ---- where the two halves of this block go ------------------------------------------------------------------
-    // chunk q = [centre(q-1), centre(q)): left-half sample j of this block sits at j + L - M, L = prev/4 + n/4 frames
-    const uint32_t emit = halo ? 0u : pi.emit;
-    float* const outq = plane + pi.out_pos;
-    // natural frames of the chunk: what the layout kernel derived emit from (emit may be clipped by the page granule)
-    const uint32_t Lq = prev_half ? prev_half / 2u + M / 2u : 0u;
-    const int32_t left_shift = (int32_t)Lq - (int32_t)M;
-    // right half: into the next chunk (only if this wave also owns it, or this is the halo), or into the carry buffer
-    const bool store_right = last_of_segment || (q + 1 < qb);
-    float* const nxt = last_of_segment ? carry_out : plane + pin.out_pos;
-    const uint32_t nlimit = last_of_segment ? M : ((q + 1 >= qa) ? pin.emit : 0u);
-
-    if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT / the next packet may reuse it
+    const bool last_of_segment = q == num - 1;
+    // MIXED: does this wave go on to the next packet with a block of the other size? (then the right half changes hands
+    // through the carry image; at the end of the run the next run's wave recomputes this block as its halo)
+    const bool hand_over = MIXED && has_next && !pin.bad && (nlng != lng);
     if (lng) {
-      // ---- IMDCT (as in fused_run) ----
+      floor_product(true);
+      // ---- IMDCT: mirror exchange, pre-rotation, FFT-512, post-rotation -------------------------------------
       float2 z[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const float im = __shfl(r[7 - t].y, (int)mirror);
+        const float im = __shfl(r[7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
         z[t] = cmulf(f2(r[t].x, im), T.pre[t][lane]);
       }
+      if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT may reuse it
+#ifdef VSYN_EXP_SETPRIO
+      __builtin_amdgcn_s_setprio(VSYN_EXP_SETPRIO);
+#endif
       fft512_wave(z, xb, &T, lane);
-      const float (*TL)[8][64] = T.win[pi.widx & 1u];
-      const float (*TN)[8][64] = T.win[(pi.widx >> 1) & 1u];
+#ifdef VSYN_EXP_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post[k][lane]);
+
+      // ---- window + overlap-add + PCM store (hpp:1008-1059) --------------------------------------------------
+      // point m = kappa + 64k gives samples s and 1023-s of this packet's output:
+      //   out[s]      = fl(P*wr(s))      + fl( cc*wl(s))        cc =  u_cur[512+s]
+      //   out[1023-s] = fl(P*wr(1023-s)) + fl(-cc*wl(1023-s))   P  = -u_prev[511-s]
+      // Handled as four point pairs (k, 7-k): each pair yields the contiguous samples (s, s+1) and (1022-s, 1023-s)
+      // after one exchange with the mirror lane. Computed for halo / first packets too (emit == 0): only the stores are
+      // guarded. P is zero until the run has seen a block; 0*w + x == x exactly as in `buf = 0; buf += x`.
+      const float (*TL)[8][64] = T.win[pi.widx & 1u];    // this block's left-half window
+      const float (*TR)[8][64] = T.win[prev_next_long];  // previous block's right-half window, mirrored
+      // chunk of this block = [centre of the previous block, centre of this one): left-half sample s sits at frame s + shift
+      const uint32_t shift = (!MIXED || prev_half != 128u) ? 0u : 0u - 448u;
+      const bool fast_store = emit == ML && (!MIXED || shift == 0u) && (((uintptr_t)out & 7u) == 0);
+      float oh_s[4], oh_m[4], n_s[4], n_m[4];
+      // window values of this lane's 8 points: left half of this block and mirrored right half of the previous one. Between
+      // two long blocks that is the same table (wave-uniform test): read it once.
+      float wl0[8], wl1[8], wr0[8], wr1[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float2 d = cmulf(z[k], T.post[k][lane]);
-        const uint32_t m = kappa + 64u * k;
-        const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m, sm = 1023u - s;
-        const float cc = k >= 4 ? d.x : -d.y, pn = k >= 4 ? d.y : -d.x;
-        const float vl_s = cc * TL[0][k][lane], vl_m = (-cc) * TL[1][k][lane];
-        const int32_t ps = (int32_t)s + left_shift, pm = (int32_t)sm + left_shift;
-        if (ps >= 0 && (uint32_t)ps < emit) outq[ps] = ((uint32_t)ps < prev_half ? outq[ps] : 0.f) + vl_s;
-        if (pm >= 0 && (uint32_t)pm < emit) outq[pm] = ((uint32_t)pm < prev_half ? outq[pm] : 0.f) + vl_m;
-        if (store_right) {
-          if (s < nlimit) nxt[s] = pn * TN[1][k][lane];
-          if (sm < nlimit) nxt[sm] = pn * TN[0][k][lane];
+        wl0[k] = TL[0][k][lane];
+        wl1[k] = TL[1][k][lane];
+      }
+      if (MIXED && prev_kind != K_REG) {
+        // The overlap term arrives already windowed: as P = 1, "window" = the value itself (1 * x == x exactly), so that
+        // the arithmetic below is the same straight-line code in every case.
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          P[k] = 1.f;
+          wr0[k] = 0.f;
+          wr1[k] = 0.f;
+        }
+        if (prev_kind == K_LDS) {
+          // after a short block: its 128 windowed samples meet this block's samples 448..575 — point 7 of the lanes with
+          // kappa >= 32 (s = 2 kappa + 384) and point 0 of the others (s = 511 - 2 kappa), both s and 1023-s
+          const bool up = kappa >= 32u;
+          const float c0 = cbuf[up ? 2u * kappa - 64u : 63u - 2u * kappa];   // at s
+          const float c1 = cbuf[up ? 191u - 2u * kappa : 64u + 2u * kappa];  // at 1023-s
+          wr1[7] = up ? c0 : 0.f;
+          wr0[7] = up ? c1 : 0.f;
+          wr1[0] = up ? 0.f : c0;
+          wr0[0] = up ? 0.f : c1;
+        } else {  // K_CARRY: a long carry-in, natural order
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t m = kappa + 64u * k;
+            const uint32_t sk = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
+            wr1[k] = cin[sk];
+            wr0[k] = cin[1023u - sk];
+          }
+        }
+      } else if (TR == TL) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          wr0[k] = wl0[k];
+          wr1[k] = wl1[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          wr0[k] = TR[0][k][lane];
+          wr1[k] = TR[1][k][lane];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kh = 4 + j, kl = 3 - j;  // kh: even sample s = 2m-512 (own), kl: odd sample 511-2m (goes to the mirror lane)
+        const float cch = z[kh].x, ccl = -z[kl].y;
+        const float ah_s = P[kh] * wr1[kh], ah_m = P[kh] * wr0[kh], al_s = P[kl] * wr1[kl], al_m = P[kl] * wr0[kl];
+        oh_s[j] = ah_s + cch * wl0[kh];
+        oh_m[j] = ah_m + (-cch) * wl1[kh];
+        const float ol_s = al_s + ccl * wl0[kl];
+        const float ol_m = al_m + (-ccl) * wl1[kl];
+        P[kh] = z[kh].y;
+        P[kl] = -z[kl].x;
+        // partner point 511 - m of (this lane, kh) is (mirror lane, slot kl): it yields samples s+1 and 1022-s
+        n_s[j] = __shfl(ol_s, 63 - (int)lane);
+        n_m[j] = __shfl(ol_m, 63 - (int)lane);
+      }
+      // sample s = 2*kappa + 128*j of (lane, kh = 4 + j): two lane pointers, every store at an immediate offset
+      if (fast_store) {
+        float* up = out + 2u * kappa;            // samples s, s+1
+        float* dn = out + 1022u - 2u * kappa;    // samples 1022-s, 1023-s
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          *(float2*)(up + 128 * j) = f2(oh_s[j], n_s[j]);
+          *(float2*)(dn - 128 * j) = f2(n_m[j], oh_m[j]);
+        }
+      } else if (emit) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // frames of samples s, s+1, 1022-s, 1023-s (a frame before the chunk wraps around and is never < emit)
+          const uint32_t s = 2u * kappa + 128u * j;
+          const uint32_t f0 = s + shift, f1 = s + 1u + shift, f2m = 1022u - s + shift, f3m = 1023u - s + shift;
+          if (f0 < emit) out[f0] = oh_s[j];
+          if (f1 < emit) out[f1] = n_s[j];
+          if (f2m < emit) out[f2m] = n_m[j];
+          if (f3m < emit) out[f3m] = oh_m[j];
+        }
+      }
+      if (last_of_segment || hand_over) {
+        // the windowed right half in natural order: sample s of point k at position s.  Last block of the segment: all of it
+        // into the stream's carry buffer for the next submit.  Before a short block: frames 0..447 are final (nothing else
+        // lands there) and go into the next chunk, frames 448..575 into the carry image, the rest is windowed to zero.
+        const size_t carry_half = (size_t)H->max_streams * C * ML;
+        float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * ML;
+        float* nxt = plane + pin.out_pos;
+        const float (*TN)[8][64] = T.win[cur_next_long];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t m = kappa + 64u * k;
+          const uint32_t s = k >= 4 ? 2u * m - 512u : 511u - 2u * m;
+          const float v_s = P[k] * TN[1][k][lane], v_m = P[k] * TN[0][k][lane];
+          if (last_of_segment) {
+            cout[s] = v_s;
+            cout[1023u - s] = v_m;
+          } else {
+            const uint32_t sm = 1023u - s;
+            if (s < 448u) {
+              if (s < pin.emit) nxt[s] = v_s;
+            } else if (s < 576u) {
+              cbuf[s - 448u] = v_s;
+            }
+            if (sm < 448u) {
+              if (sm < pin.emit) nxt[sm] = v_m;
+            } else if (sm < 576u) {
+              cbuf[sm - 448u] = v_m;
+            }
+          }
         }
       }
     } else {
-      // ---- short block: one point per lane ----
-      const float im = __shfl(r[0].y, (int)mirror);  // X[127 - 2k] lives in lane 63-k
+      // ---- short block: one complex point per lane ------------------------------------------------------------
+      floor_product(false);
+      const float im = __shfl(r[0].y, 63 - (int)lane);  // X[127 - 2k] lives in lane 63-k
       float2 z = cmulf(f2(r[0].x, im), T.pre_s[lane]);
+      if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the next packet may reuse it
 #pragma unroll
       for (int i = 0; i < 6; ++i) {  // radix-2 decimation in frequency across lanes: partner l ^ d, d = 32 .. 1
         const int d = 32 >> i;
@@ -687,16 +629,38 @@ __device__ __forceinline__ void fused_mixed_run(const FusedArgs& A, const FusedL
       const bool hi = m >= 32u;
       const uint32_t s = hi ? 2u * m - 64u : 63u - 2u * m, sm = 127u - s;
       const float cc = hi ? d.x : -d.y, pn = hi ? d.y : -d.x;
-      const float vl_s = cc * T.wsl[0][lane], vl_m = (-cc) * T.wsl[1][lane];
-      const int32_t ps = (int32_t)s + left_shift, pm = (int32_t)sm + left_shift;
-      if (ps >= 0 && (uint32_t)ps < emit) outq[ps] = ((uint32_t)ps < prev_half ? outq[ps] : 0.f) + vl_s;
-      if (pm >= 0 && (uint32_t)pm < emit) outq[pm] = ((uint32_t)pm < prev_half ? outq[pm] : 0.f) + vl_m;
-      if (store_right) {
-        if (s < nlimit) nxt[s] = pn * T.wsl[1][lane];
-        if (sm < nlimit) nxt[sm] = pn * T.wsl[0][lane];
+      // overlap terms: a short block before (same lanes), or the carry image (after a long block / a carry-in)
+      float a_s, a_m;
+      if (prev_kind == K_LDS) {
+        a_s = cbuf[s];
+        a_m = cbuf[sm];
+      } else {
+        a_s = Ps * T.wsl[1][lane];
+        a_m = Ps * T.wsl[0][lane];
+      }
+      const uint32_t shift = prev_half == ML ? 448u : 0u;  // after a long block the chunk starts with its 448 frames
+      const float o_s = a_s + cc * T.wsl[0][lane], o_m = a_m + (-cc) * T.wsl[1][lane];
+      if (s + shift < emit) out[s + shift] = o_s;
+      if (sm + shift < emit) out[sm + shift] = o_m;
+      Ps = pn;
+      if (last_of_segment) {
+        const size_t carry_half = (size_t)H->max_streams * C * ML;
+        float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * ML;
+        cout[s] = pn * T.wsl[1][lane];
+        cout[sm] = pn * T.wsl[0][lane];
+      } else if (hand_over) {
+        cbuf[s] = pn * T.wsl[1][lane];
+        cbuf[sm] = pn * T.wsl[0][lane];
       }
     }
-    prev_half = M;
+    if (MIXED) {
+      prev_kind = hand_over ? K_LDS : K_REG;
+      prev_half = M;  // (registers of the other size are never consulted: a size change always goes through K_LDS, and a
+                      //  skipped packet clears both)
+    }
+    if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
+    prev_next_long = cur_next_long;
+    pi = pin;
   }
 }
 
@@ -704,7 +668,7 @@ static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a
 // ONE launch for both kinds of run. grid: x = groups of FUSED_WAVES (run, channel) units — the channels of a run sit in
 // adjacent waves of one workgroup, which is what the pairwise LDS hand-off needs —, y = segment. Every wave looks up the
 // class the layout kernel gave its run (1: all long blocks, steady windows, no carry-in -> fused_run; 2: anything else the
-// fused paths cover -> fused_mixed_run) and takes that path; waves of one workgroup may take different ones (they only ever
+// fused paths cover -> fused_run<.., MIXED = true>) and takes that path; waves of one workgroup may take different ones (they only ever
 // meet their coupling partner, which shares the run and therefore the class).
 __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_kernel(const FusedArgs A) {
   // one LDS block with a fixed member order: the floor entry tables come first so that their addresses fit the 16 bits
@@ -729,7 +693,7 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   const vsyn_segment sg = A.segs[g];
   if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // whole workgroup: the layout kernel flagged the segment
   const uint32_t unit = blockIdx.x * FUSED_WAVES + wave;
-  const uint32_t run = unit / C, c = unit % C;
+  const uint32_t run = __builtin_amdgcn_readfirstlane(unit / C), c = __builtin_amdgcn_readfirstlane(unit % C);  // (the division runs on the vector unit)
   const uint32_t qa = run * A.R;
   const uint32_t qb = min(sg.num_packets, qa + A.R);
   const SegInfo si = A.sinfo[g];
@@ -750,14 +714,17 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   const uint32_t pw = role ? (wave ^ 1u) : wave;  // partner wave
   lds_u32* mf = (lds_u32*)s_flag[wave];
   const lds_u32* pf = (const lds_u32*)s_flag[pw];
+  // mixed runs: the 128 overlap frames that change hands when the block size changes live in the second half of the wave's
+  // floor-entry block (the entries are 8 bytes: 64 of them fill the first 512 bytes)
+  lds_f32* cbw = (lds_f32*)((float*)s_seg[wave] + 128);
   if (cls == 1u) {
-    if (role == 0) fused_run<0>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, c);
-    else if (role == 1) fused_run<1>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
-    else fused_run<2>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
+    if (role == 0) fused_run<0, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, c);
+    else if (role == 1) fused_run<1, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
+    else fused_run<2, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
   } else {
-    if (role == 0) fused_mixed_run<0>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, c);
-    else if (role == 1) fused_mixed_run<1>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
-    else fused_mixed_run<2>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
+    if (role == 0) fused_run<0, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, c);
+    else if (role == 1) fused_run<1, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
+    else fused_run<2, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
   }
 }
 
@@ -881,6 +848,7 @@ static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t
   int blocks = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vsyn_fused_kernel, FUSED_WAVES * 64, 0) == hipSuccess && blocks > 0)
     ft->waves_per_cu = blocks * FUSED_WAVES;
+  if (getenv("VSYN_DEBUG")) fprintf(stderr, "vsyn: fused kernel %d workgroups/CU -> %d waves/CU\n", blocks, ft->waves_per_cu);
   return hipSuccess;
 }
 
