@@ -130,7 +130,7 @@ struct vsyn_handle {
   DevBuf<uint32_t> st_emit;
   // profiling
   bool profile = false;
-  int profile_which = 1;  // 1: long-run fused kernel, 2: mixed-block fused kernel, 3: residue VQ kernel
+  int profile_which = 1;  // 1 / 2: the fused kernel (steady / mixed workloads: same kernel), 3: residue VQ kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   const char* profile_kernel = "";

@@ -40,7 +40,7 @@ struct FusedLdsImage {
   float win[2][2][8][64]; // [prev/next flag][0: at s, 1: at 1023-s][k][lane]: left half of the long window at the
                           // output sample s of point m; the right half for next flag f is its mirror (hpp:850-859)
   float invdb[260];       // Vorbis I 10.1 (hpp:588); [255] == 1.0f, extra [256] == 0.0f (see floor product)
-  // short blocks (blocksize0 == 256: 64 complex points, one per lane; used by the mixed-block kernel only)
+  // short blocks (blocksize0 == 256: 64 complex points, one per lane; used by mixed-block runs only)
   float2 pre_s[64];       // pre-rotation of point k = lane
   float2 post_s[64];      // post-rotation of bin m = bitrev6(lane)
   float2 tws[6][64];      // DIF stage twiddles: stage i pairs lane l with l ^ (32 >> i); W_(64>>i)^(l & ((32>>i)-1))
@@ -62,14 +62,14 @@ struct FusedArgs {
   const vsyn_segment* segs;
   const PktInfo* info;
   const SegInfo* sinfo;
-  const uint8_t* run_cls;  // [S][runs_per_seg] from the layout kernel: 1 long-run kernel, 2 mixed kernel, 0 staged, 0xFF none
+  const uint8_t* run_cls;  // [S][runs_per_seg] from the layout kernel: 1 steady long run, 2 mixed-block run, 0 staged, 0xFF none
   const float* residue;
   const uint16_t* fy;
   float* pcm;
   float* carry;
   DevStatus* status;
   uint64_t plane_stride;
-  uint32_t S, R, fused_ok, coupling_mode, runs_per_seg;  // fused_ok: bit 0 long-run kernel, bit 1 mixed-block kernel
+  uint32_t S, R, fused_ok, coupling_mode, runs_per_seg;  // fused_ok: bit 0 steady long runs, bit 1 mixed-block runs
 };
 
 __device__ __forceinline__ float2 f2(float x, float y) { return make_float2(x, y); }
@@ -751,7 +751,7 @@ static inline int fused_coupling_mode(const ConstHeader& H, const uint8_t* host_
   return mode == -2 ? 0 : mode;
 }
 
-// bit 0: long-run kernel usable, bit 1: mixed-block kernel usable (needs blocksize0 == 256 and the same coupling
+// bit 0: steady long runs usable, bit 1: mixed-block runs usable (needs blocksize0 == 256 and the same coupling
 // structure in every mapping, short-block modes included)
 static inline uint32_t fused_ok_mask(const ConstHeader& H, const uint8_t* host_const);
 

@@ -133,8 +133,51 @@ def test_streaming_across_submits(flags):
     got = np.concatenate(parts, axis=1)
     if flags:  # staged kernels everywhere: same arithmetic, same bits
         assert np.array_equal(got, one["pcm"][0][:, :total])
-    else:      # a run that continues a stream from an earlier submit takes the staged kernels, the rest the fused one
+    else:      # fused kernel: the carry of a cut is the same rounded product the uncut run keeps in registers
         assert np.abs(got - one["pcm"][0][:, :total]).max() < TOL
+
+
+@pytest.mark.parametrize("seed,run_len", [(1, 4), (2, 5), (3, 7), (4, 0)])
+def test_random_block_patterns_runs_and_cuts(seed, run_len, monkeypatch):
+    """The fused kernel's mixed-block path: random bursts of short blocks, short runs (so that run boundaries and their
+    one-packet halos fall on every kind of transition), then the same streams cut into several submits at random places
+    (carry-in long->long, long->short, short->short, short->long). One submit == oracle; cut == uncut, bit for bit."""
+    rng = np.random.default_rng(100 + seed)
+    npk = 90
+    flags = np.ones(npk, np.uint8)
+    q = 0
+    while q < npk:  # alternating stretches: long 1..6, short 1..9
+        q += int(rng.integers(1, 7))
+        k = int(rng.integers(1, 10))
+        flags[q:q + k] = 0
+        q += k
+    if run_len:
+        monkeypatch.setenv("VSYN_RUN_LEN", str(run_len))
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, 3, npk, flags, seed=seed, unused_frac=0.15, granule_last=True)
+    want = ob.OracleSynth(spec, 3).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    one = binding.Synth(spec, max_streams=3).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    check(one, want)
+    # stream 0 again, cut at random places (every kind of size pair occurs at some cut)
+    n_of = np.where(b["packets"]["mode"][:npk] == 1, spec.blocksize1, spec.blocksize0)
+    off = np.concatenate([[0], np.cumsum(2 * n_of // 2)])
+    first_of = {}
+    for c in range(npk - 1, 0, -1):
+        first_of[(int(flags[c - 1]), int(flags[c]))] = c
+    assert len(first_of) == 4
+    cuts = sorted(set([0, npk] + [int(c) for c in rng.integers(1, npk, 12)] + list(first_of.values())))
+    gpu = binding.Synth(spec, max_streams=2)
+    parts = []
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        seg = b["segments"][:1].copy()
+        seg["stream"], seg["first_packet"], seg["num_packets"], seg["flags"], seg["residue_off"] = 1, 0, e - a, 1 if a == 0 else 0, 0
+        r = gpu.submit_host(b["packets"][a:e], seg, b["ys"][a:e], b["residue"][off[a]:off[e]], b["plane_stride"])
+        assert r["rc"] == 0
+        assert np.array_equal(r["emit_len"], one["emit_len"][a:e])
+        parts.append(r["pcm"][0][:, :int(r["emit_len"].sum())])
+    got = np.concatenate(parts, axis=1)
+    total = int(one["emit_len"][:npk].sum())
+    assert np.array_equal(bits(got), bits(one["pcm"][0][:, :total]))
 
 
 def test_empty_and_ragged_batches():

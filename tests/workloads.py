@@ -94,11 +94,16 @@ def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, yl
                 granule_last=False, roll=True):
     """Synthetic batch in the shape of BASELINE configs 3/4:
     residue = round(Laplace(b=1.5)) with 60 % zeros; floor amplitudes a random walk in [ylo,yhi] (step +-6)
-    over the setup's X list, wrapped into coded ys.  pattern: 'long', 'short' or 'mixed' (L L L S*8 repeating).
+    over the setup's X list, wrapped into coded ys.  pattern: 'long', 'short', 'mixed' (L L L S*8 repeating, rotated per
+    stream) or an explicit sequence of block flags (1 = long), the same for every stream.
     Returns dict(packets, segments, ys, residue, plane_stride)."""
     rng = np.random.default_rng(seed)
     C = spec.channels
-    if pattern == "long":
+    if not isinstance(pattern, str):
+        flags1 = np.asarray(pattern, np.uint8)
+        assert len(flags1) == packets_per_stream
+        roll = False
+    elif pattern == "long":
         flags1 = np.ones(packets_per_stream, np.uint8)
     elif pattern == "short":
         flags1 = np.zeros(packets_per_stream, np.uint8)
@@ -115,7 +120,7 @@ def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, yl
     res_parts = []
     off = 0
     for s in range(streams):
-        flags = flags1 if (pattern != "mixed" or not roll) else np.roll(flags1, s % 11)
+        flags = flags1 if (not roll or pattern != "mixed") else np.roll(flags1, s % 11)
         seg[s] = (s, s * packets_per_stream, packets_per_stream, VSYN_SEG_RESET, off)
         for q in range(packets_per_stream):
             p = s * packets_per_stream + q
@@ -145,7 +150,7 @@ def synth_batch(spec, streams, packets_per_stream, pattern="long", seed=1234, yl
             off += C * (n // 2)
     if granule_last:
         for s in range(streams):
-            fl = flags1 if (pattern != "mixed" or not roll) else np.roll(flags1, s % 11)
+            fl = flags1 if (not roll or pattern != "mixed") else np.roll(flags1, s % 11)
             sizes = np.where(fl, spec.blocksize1, spec.blocksize0)
             total = int(sum(sizes[i - 1] // 4 + sizes[i] // 4 for i in range(1, packets_per_stream)))
             last_l = int(sizes[-2] // 4 + sizes[-1] // 4) if packets_per_stream > 1 else 0
