@@ -86,6 +86,9 @@ def main():
                     help="config3_vq: config 3 with the residue given as VQ entry numbers (device VQ stage, SURVEY 8 f-1)")
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--packets-per-stream", type=int, default=0)
+    ap.add_argument("--vq-books", default="synthetic", choices=["synthetic", "fixture"],
+                    help="config3_vq: codebooks and entry streams — a synthetic setup in the fixture's shape, or the stereo fixture's own "
+                         "codebooks with its long packets' classifications / entry numbers replicated (tests/golden/test.stereo44khz.ogg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--staged", action="store_true", help="time the staged kernels instead of the fused one")
     ap.add_argument("--no-overlap", action="store_true",
@@ -143,10 +146,30 @@ def main():
             # same batch, but "after_residue" is rebuilt on the device from classification + entry numbers
             from tests.workloads import synthetic_vq_spec, synth_vq_packet
             from parseoggvorbis_amd.binding import VQ_PACKET_DTYPE
-            vqs = synthetic_vq_spec(spec.channels, spec.blocksize1)
-            gpu.attach_vq(vqs)
             rng = np.random.default_rng(77 + rank)
-            pool = [synth_vq_packet(vqs, 1, spec.channels, spec.blocksize1 // 2, 3, rng) for _ in range(256)]
+            if args.vq_books == "fixture":
+                # the host decoder's entropy half over the real file (tests/host_entropy_dump.cpp): real codebooks (the 8 x 6561
+                # lattice book among them), real class / entry statistics
+                import subprocess
+                import tempfile
+                from tests.workloads import GOLDEN, build_probe, read_entropy_dump
+                td = tempfile.mkdtemp()
+                probe = build_probe(td)
+                subprocess.run([probe, os.path.join(GOLDEN, "test.stereo44khz.ogg"), os.path.join(td, "d.bin")], check=True, capture_output=True)
+                d = read_entropy_dump(os.path.join(td, "d.bin"))
+                vqs = d["vq_spec"]
+                fp = d["vq_packets"]
+                pool = []
+                for k in range(d["P"]):
+                    if int(d["packets"]["mode"][k]) != 1:
+                        continue
+                    c0, e0, ne = int(fp["cls_off"][k]), int(fp["entry_off"][k]), int(fp["num_entries"][k])
+                    c1 = int(fp["cls_off"][k + 1]) if k + 1 < d["P"] else d["cls"].size
+                    pool.append((d["cls"][c0:c1].copy(), d["entries"][e0:e0 + ne].copy()))
+            else:
+                vqs = synthetic_vq_spec(spec.channels, spec.blocksize1)
+                pool = [synth_vq_packet(vqs, 1, spec.channels, spec.blocksize1 // 2, 3, rng) for _ in range(256)]
+            gpu.attach_vq(vqs)
             pick = rng.integers(0, len(pool), b["P"])
             cls = np.concatenate([pool[i][0] for i in pick])
             ent = np.concatenate([pool[i][1] for i in pick])
@@ -189,8 +212,9 @@ def main():
             # the roofline object of this workload describes the residue VQ kernel: entry + classification numbers and
             # the two 16/32-byte descriptors in, the rebuilt residue out
             bytes_per_unit = vq_entries_per_packet * 2 + float(cls.size) / b["P"] + 16 + 32 + spec.channels * (spec.blocksize1 // 2) * 4
-            wl = ("config3_vq: config 3 with the residue as VQ entry numbers (%.0f entries/packet, synthetic format-2 setup); "
-                  "residue VQ kernel + synthesis" % vq_entries_per_packet)
+            wl = ("config3_vq: config 3 with the residue as VQ entry numbers (%.0f entries/packet, %s); "
+                  "residue VQ kernel + synthesis" % (vq_entries_per_packet, "synthetic format-2 setup" if args.vq_books == "synthetic"
+                                                     else "the stereo fixture's codebooks and long-packet entry streams"))
 
     def barrier():
         if world > 1:

@@ -178,3 +178,39 @@ def test_vq_stage_reports_bad_streams(probe, tmp_path):
     res[0]["partition_size"] = 7
     with pytest.raises(VsynError, match="divide"):
         syn.attach_vq(VqSpec(books, res, d["vq_spec"].mappings))
+
+
+def test_vq_stage_survives_garbage(probe, tmp_path):
+    """Untrusted input: random classification bytes, random entry numbers, descriptors whose counts do not match. The stage
+    must flag the packets (or, by luck, accept them), never read outside what it was given, and be exact again on the next
+    clean batch."""
+    spec, _, _ = load_golden("test.stereo44khz")
+    d = _dump(probe, "test.stereo44khz", tmp_path)
+    pk, seg, vqp, cls, ent, want = _random_vq_batch(spec, d["vq_spec"], 4, 12, [1, 0, 1, 1], seed=11)
+    syn = Synth(spec, max_streams=4)
+    syn.attach_vq(d["vq_spec"])
+    ys = np.zeros((len(pk), 2, syn.ys_stride), np.uint16)
+    rng = np.random.default_rng(5)
+    flagged = 0
+    for trial in range(12):
+        c2, e2, v2 = cls.copy(), ent.copy(), vqp.copy()
+        kind = trial % 4
+        if kind == 0:
+            c2[:] = rng.integers(0, 256, c2.size)
+        elif kind == 1:
+            e2[:] = rng.integers(0, 65536, e2.size)
+        elif kind == 2:
+            hit = rng.random(c2.size) < 0.05
+            c2[hit] = rng.integers(0, 256, int(hit.sum()))
+            hit = rng.random(e2.size) < 0.05
+            e2[hit] = rng.integers(0, 65536, int(hit.sum()))
+        else:  # counts / offsets that do not describe the stream (still inside the arrays, which the host checks)
+            v2["num_entries"] = rng.integers(0, 3000, len(v2))
+            v2["entry_off"] = rng.integers(0, max(1, e2.size - 3000), len(v2))
+            v2["cls_off"] = rng.integers(0, c2.size, len(v2))
+        out = syn.submit_host_vq(pk, seg, ys, v2, c2, e2, want.size, 12 * 1024)
+        assert out["rc"] in (0, VSYN_ERR_STREAM)
+        flagged += out["rc"] == VSYN_ERR_STREAM and bool(out["flags"] & VSYN_ST_BAD_VQ)
+        clean = syn.submit_host_vq(pk, seg, ys, vqp, cls, ent, want.size, 12 * 1024)
+        assert clean["rc"] == 0 and np.array_equal(clean["residue"].view(np.uint32), want.view(np.uint32))
+    assert flagged >= 9
