@@ -290,3 +290,39 @@ def test_device_resident_back_to_back_submits_overlap_safely():
         want = orc.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
         assert np.array_equal(d["emit"].cpu().numpy().astype(np.uint32), want["emit_len"])
         assert np.abs(d["pcm"].cpu().numpy() - want["pcm"]).max() < TOL
+
+
+@pytest.mark.parametrize("flags", PATHS)
+def test_garbage_descriptors_and_posts(flags):
+    """Untrusted input: random mode numbers / window flags / granules / floor-used masks and random coded posts. Whatever the
+    verdict (the oracle gives the same one), nothing is read or written outside the batch and the handle is exact again on the
+    next clean batch."""
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, 3, 40, "mixed", seed=8)
+    gpu = binding.Synth(spec, max_streams=3)
+    orc = ob.OracleSynth(spec, 3)
+    rng = np.random.default_rng(17)
+    for trial in range(8):
+        pk = b["packets"].copy()
+        ys = b["ys"].copy()
+        hit = rng.random(len(pk)) < (0.08 if trial % 2 else 0.5)
+        raw = pk.view(np.uint8).reshape(len(pk), -1)
+        raw[hit] = rng.integers(0, 256, (int(hit.sum()), raw.shape[1]), dtype=np.uint8)
+        if trial >= 4:
+            yh = rng.random(ys.shape) < 0.1
+            ys[yh] = rng.integers(0, 65536, int(yh.sum()))
+        # the residue layout follows the (possibly changed) modes: give every packet room for a long block
+        seg = b["segments"].copy()
+        res = np.zeros(len(pk) * 2 * (spec.blocksize1 // 2) + 64, np.float32)
+        res[:b["residue"].size] = b["residue"]
+        per = len(pk) // len(seg) * 2 * (spec.blocksize1 // 2)
+        seg["residue_off"] = np.arange(len(seg), dtype=np.uint64) * per
+        r = gpu.submit_host(pk, seg, ys, res, b["plane_stride"] + 40 * 1024, flags=flags)
+        w = orc.submit_host(pk, seg, ys, res, b["plane_stride"] + 40 * 1024)
+        assert (r["rc"] == 0) == (w["rc"] == 0), (trial, r["rc"], w["rc"], r["flags"], w["flags"])
+        gpu.reset()
+        orc = ob.OracleSynth(spec, 3)
+        check(gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=flags),
+              orc.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"]))
+        gpu.reset()
+        orc = ob.OracleSynth(spec, 3)
