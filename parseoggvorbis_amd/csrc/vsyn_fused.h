@@ -202,9 +202,9 @@ __device__ __forceinline__ PktScalars pkt_load(const PktInfo* p) {  // p wave-un
 }
 
 // The whole per-wave job: the run [qa, qb) of segment g, output channel c.
-// ROLE: 0 channel c is not coupled; 1 c is the magnitude channel of the (single) coupling step, `pc` its angle
-// partner; 2 c is the angle channel, `pc` the magnitude partner. A coupled wave loads both channels' residue and
-// keeps only its own side of hpp:1219-1240 (5 VALU per bin instead of 7 for both).
+// ROLE: 0 channel c is not coupled; 1 c is the magnitude channel of the (single) coupling step; 2 c is the angle channel.
+// A coupled wave gets the partner channel's residue from the partner wave's exchange image (`pxb`) and keeps only its own
+// side of hpp:1219-1240 (5 VALU per bin instead of 7 for both).
 //
 // MIXED = false: every block of the run (halo included) is long and there is no carry-in — the steady state, nothing below
 // about short blocks is compiled in.  MIXED = true: short blocks (n = 256: one complex point per lane, FFT-64 as six
@@ -223,8 +223,7 @@ __device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26
 template <int ROLE, bool MIXED>
 __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb, float4* __restrict__ seg,
                                           lds_f32* cbuf, lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane0, const uint32_t g,
-                                          const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c,
-                                          const uint32_t pc) {
+                                          const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c) {
   constexpr uint32_t ML = 1024;
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
@@ -709,7 +708,7 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   }
   __syncthreads();  // the only workgroup-wide barrier: from here on a wave meets nobody but its coupling partner (pair_post/pair_wait)
   if (!active) return;  // a run is active for all its channels or for none: no partner is left waiting
-  const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u, ang = mag ^ 1u;
+  const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u;  // the magnitude channel of the (single) coupling step
   const int role = (A.coupling_mode == 0 || C < 2) ? 0 : (c == mag ? 1 : 2);
   const uint32_t pw = role ? (wave ^ 1u) : wave;  // partner wave
   lds_u32* mf = (lds_u32*)s_flag[wave];
@@ -718,13 +717,13 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   // floor-entry block (the entries are 8 bytes: 64 of them fill the first 512 bytes)
   lds_f32* cbw = (lds_f32*)((float*)s_seg[wave] + 128);
   if (cls == 1u) {
-    if (role == 0) fused_run<0, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, c);
-    else if (role == 1) fused_run<1, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
-    else fused_run<2, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
+    if (role == 0) fused_run<0, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else if (role == 1) fused_run<1, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else fused_run<2, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
   } else {
-    if (role == 0) fused_run<0, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, c);
-    else if (role == 1) fused_run<1, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, ang);
-    else fused_run<2, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c, mag);
+    if (role == 0) fused_run<0, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else if (role == 1) fused_run<1, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else fused_run<2, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
   }
 }
 

@@ -138,7 +138,6 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   if (qb > 0 && qb < num) carry_prev_mode = spk[qb - 1].mode;
   __syncthreads();
   auto n_of_mode = [&](uint32_t m) -> uint32_t { return (m < num_modes && s_bf[m]) ? bs1 : bs0; };
-  auto block_n = [&](uint32_t q) -> uint32_t { return n_of_mode(spk[q].mode); };
 
   // pass A: per-thread aggregate
   AbsScan agg = {0, 0};

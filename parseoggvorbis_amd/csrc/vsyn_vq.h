@@ -139,7 +139,7 @@ struct VqSubCtx {
 // The accumulate phase: a lane owns VQ_GROUP consecutive elements of one partition of one vector and adds their up-to-8
 // contributions in pass order (hpp:711) in registers. ENT_LDS: the packet's entries sit in s_ent, otherwise in eg[].
 template <bool ENT_LDS>
-__device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t lane, const bool bad, const uint32_t vused, const VqCp* s_cp,
+__device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t lane, const bool bad, const VqCp* s_cp,
                                                const uint16_t* s_pp, const vq_u32x4* s_start, const uint16_t* s_ent, const uint8_t* s_vm,
                                                const uint8_t* s_cls, const uint8_t* s_chan, const uint16_t* __restrict__ eg,
                                                const float* __restrict__ pool, float* __restrict__ out) {
@@ -442,8 +442,8 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
 
       // ---- accumulate + store ----
       bool bad_entry;
-      if (ent_lds) bad_entry = vq_accumulate<true>(X, lane, bad, vused, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
-      else bad_entry = vq_accumulate<false>(X, lane, bad, vused, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
+      if (ent_lds) bad_entry = vq_accumulate<true>(X, lane, bad, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
+      else bad_entry = vq_accumulate<false>(X, lane, bad, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
       if (bad_entry) raise_status(status, VSYN_ST_BAD_VQ, p);
 
       // elements outside the partitions stay zero (hpp:1186-1190): [0, lim_begin) and [lim_begin + parts * psize, len) of every
