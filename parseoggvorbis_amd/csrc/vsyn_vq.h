@@ -30,7 +30,8 @@
 // memory inside the accumulate loop, per-pass LDS book records, zero fill element by element) 0.48 ms; earlier alternatives:
 // workgroup of 128/256 threads per packet 0.67-0.88 ms; separate scan + accumulate kernels (thread = element group, no
 // per-packet loop) 0.69 ms; thread = one entry of a pass with f32 accumulators in LDS 0.69-0.77 ms; forcing 8 waves/SIMD
-// (64 VGPRs, spills) 0.53 ms.
+// (64 VGPRs, spills) 0.53 ms.  Upper bound of sorting a packet's partitions by class before the accumulate phase (input
+// generated with the classes already sorted, i.e. without the cost of the sort): 0.26 ms — not pursued.
 #pragma once
 #include "vsyn_device.h"
 
