@@ -280,7 +280,7 @@ int vsyn_reset_streams(vsyn_handle* h, void* hip_stream, const char** err);
 
 /* Kernel timing for roofline reporting: when enabled, vsyn_submit_device brackets its dominant kernel with
  * hipEvents on hip_stream; vsyn_profile_read synchronises and returns the mean duration since the last read. */
-int vsyn_profile_enable(vsyn_handle* h, int on); /* 0 off, 1 time the long-run fused kernel, 2 the mixed-block fused kernel, 3 the residue VQ kernel */
+int vsyn_profile_enable(vsyn_handle* h, int on); /* 0 off, 1 or 2 time the fused synthesis kernel (one kernel serves steady and mixed-block runs), 3 the residue VQ kernel */
 int vsyn_profile_read(vsyn_handle* h, double* mean_ms, uint32_t* launches, const char** kernel_name);
 
 /* IMDCT-only entry (BASELINE config 2): in [count][n/2] -> out [count][n], device pointers, n = blocksize0 or blocksize1. */
