@@ -75,6 +75,74 @@ def build_batch(spec, streams, ppk, pattern, seed, device):
                 host_packets=pk, host_segments=seg, per_stream_floats=per_stream_floats, n_of=n_of)
 
 
+def run_config5(args, rank, world, local, device):
+    """BASELINE config 5: real files end to end. Every rank decodes its own shard of files — here `files_per_gpu`
+    replicas of the stereo fixture, the only real stereo file there is offline — with the product's corpus decoder
+    (parseoggvorbis_amd/host/CorpusDecoder: entropy worker threads -> merged multi-file submits on this rank's GPU). No data-path
+    collective: files are independent. Checked: every replica yields the granule-derived frame count and the same checksum."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from parseoggvorbis_amd import sharding
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = C.CDLL(os.path.join(here, "parseoggvorbis_amd", "host", "libparseoggvorbis_amd.so"))
+    lib.ogg_vorbis_decode_corpus.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                             C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_char_p)]
+    lib.ogg_vorbis_decode_corpus.restype = C.c_int
+    blob = open(os.path.join(here, "tests", "golden", "test.stereo44khz.ogg"), "rb").read()
+    gold = np.load(os.path.join(here, "tests", "golden", "test.stereo44khz.npz"))
+    want_frames = int(gold["pcm"].shape[-1])  # the reference decoder's total for this file (granule-derived, SURVEY 8b)
+    n = args.files_per_gpu
+    cores = os.cpu_count() or 16
+    threads = args.host_threads or max(2, min(16, cores // max(1, world)))
+    feeders = 4 if threads >= 12 else 2
+    datas = (C.c_char_p * n)(*([blob] * n))
+    lens = (C.c_size_t * n)(*([len(blob)] * n))
+    frames = (C.c_uint64 * n)()
+    sums = (C.c_double * n)()
+    ok = (C.c_uint8 * n)()
+    stats = (C.c_double * 8)()
+    err = C.c_char_p()
+
+    def step():
+        rc = lib.ogg_vorbis_decode_corpus(datas, lens, n, threads, feeders, 64, local, frames, sums, ok, None, None, stats, C.byref(err))
+        assert rc == 0, err.value
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    fr = np.frombuffer(frames, np.uint64)
+    sm = np.frombuffer(sums, np.float64)
+    assert np.frombuffer(ok, np.uint8).all(), "a replica failed"
+    assert (fr == want_frames).all(), "frame count differs from the granule-derived total of the fixture"
+    assert (sm == sm[0]).all(), "replicas are not bit-identical"
+    packets = int(round(stats[6]))
+    dt, total, extra = sharding.aggregate(dt, packets, device, extra_sum=(stats[1], stats[2], float(fr.sum())))
+    if rank == 0:
+        line = {"metric": "audio packets/sec", "value": round(total * args.steps / dt, 1), "unit": "packets/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "tests/golden/test.stereo44khz.ogg replicated",
+                "config": {"workload": "config5: real files end to end, %d files (%d audio packets) per GPU, %d entropy threads + %d feeders "
+                                       "per rank" % (n, packets, threads, feeders), "packets_per_gpu": packets,
+                           "parallelism": "files sharded over %d GPU(s), no data-path collective" % world},
+                "roofline": None,  # host-bound end to end: see the kernel workloads for the rooflines
+                "cpu_baseline": None,
+                "realtime_factor": round(extra[2] * args.steps / dt / 44100.0, 1),
+                "entropy_cpu_s_per_step": round(extra[0] / world, 3), "gpu_call_s_per_step": round(extra[1] / world, 3),
+                "replicas_bit_identical": True, "frames_per_file": want_frames}
+        print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,8 +150,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pcm-s16", action="store_true",
                     help="config3/config4: append the PCM post-stage (planar f32 -> interleaved int16, SURVEY 8 f-3) to every step")
-    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config2", "config3_vq"],
-                    help="config3_vq: config 3 with the residue given as VQ entry numbers (device VQ stage, SURVEY 8 f-1)")
+    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config2", "config3_vq", "config5"],
+                    help="config3_vq: config 3 with the residue given as VQ entry numbers (device VQ stage, SURVEY 8 f-1); "
+                         "config5: real .ogg files end to end (host entropy threads + GPU), files sharded over the ranks; use few steps, "
+                         "e.g. --steps 3 --warmup 1 (one step = one pass over the rank's files)")
+    ap.add_argument("--files-per-gpu", type=int, default=10640, help="config5: replicas of the stereo fixture per rank (94 audio packets each)")
+    ap.add_argument("--host-threads", type=int, default=0, help="config5: entropy worker threads per rank (0: this rank's share of the cores, at most 16)")
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--packets-per-stream", type=int, default=0)
     ap.add_argument("--vq-books", default="synthetic", choices=["synthetic", "fixture"],
@@ -107,6 +179,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, "launch with WORLD_SIZE == --gpus (one process per GPU)"
+
+    if args.workload == "config5":
+        run_config5(args, rank, world, local, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from parseoggvorbis_amd.binding import Synth, VSYN_SUBMIT_STAGED, VSYN_SUBMIT_INPUTS_READY
     from tests.workloads import fixture_like_spec

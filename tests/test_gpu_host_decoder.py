@@ -203,3 +203,18 @@ def test_corpus_survives_damaged_files(tmp_path):
     out = json.loads(r.stdout)
     assert out["files"] == 41
     assert out["first_file"]["frames"] == load_golden(names[0])[1]["pcm"].shape[1]  # the intact file is unaffected by its neighbours
+
+
+def test_bench_config5_line():
+    """bench.py --workload config5 (real files end to end) runs and prints one JSON line; it asserts itself
+    that every replica has the granule-derived frame count and the same checksum."""
+    import json
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "config5", "--files-per-gpu", "96", "--steps", "1",
+                          "--warmup", "0", "--host-threads", "4"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["config"]["packets_per_gpu"] == 96 * 94 and j["replicas_bit_identical"] and j["value"] > 0
