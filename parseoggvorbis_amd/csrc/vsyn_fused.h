@@ -664,8 +664,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 }
 
 static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a workgroup");
-// ONE launch for both kinds of run. grid: x = groups of FUSED_WAVES (run, channel) units — the channels of a run sit in
-// adjacent waves of one workgroup, which is what the pairwise LDS hand-off needs —, y = segment. Every wave looks up the
+// ONE launch for both kinds of run. grid: groups of FUSED_WAVES (segment, run, channel) units — the channels of a run sit in
+// adjacent waves of one workgroup, which is what the pairwise LDS hand-off needs. Every wave looks up the
 // class the layout kernel gave its run (1: all long blocks, steady windows, no carry-in -> fused_run; 2: anything else the
 // fused paths cover -> fused_run<.., MIXED = true>) and takes that path; waves of one workgroup may take different ones (they only ever
 // meet their coupling partner, which shares the run and therefore the class).
@@ -687,17 +687,27 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   const ConstHeader* H = hdr_of(A.cb);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t g = blockIdx.y, C = H->channels;
-  if (g >= A.S) return;
-  const vsyn_segment sg = A.segs[g];
-  if (sg.stream >= H->max_streams || (sg.residue_off & 3)) return;  // whole workgroup: the layout kernel flagged the segment
+  // unit = (segment, run, channel), flattened over the whole batch so that a workgroup's 8 waves are busy whatever the
+  // segment lengths are (a batch of many short streams has one or two units per segment). The channels of a run are adjacent
+  // units; with 2 channels an even unit is channel 0, so a coupled pair always shares a workgroup.
+  const uint32_t C = H->channels;
+  const uint32_t per_seg = A.runs_per_seg * C;
   const uint32_t unit = blockIdx.x * FUSED_WAVES + wave;
-  const uint32_t run = __builtin_amdgcn_readfirstlane(unit / C), c = __builtin_amdgcn_readfirstlane(unit % C);  // (the division runs on the vector unit)
+  const uint32_t g = __builtin_amdgcn_readfirstlane(unit / per_seg);  // (the divisions run on the vector unit)
+  const uint32_t rem = unit - g * per_seg;
+  const uint32_t run = __builtin_amdgcn_readfirstlane(rem / C), c = __builtin_amdgcn_readfirstlane(rem % C);
+  vsyn_segment sg = {};
+  SegInfo si = {};
+  uint32_t cls = 0xFFu;
+  if (g < A.S) {
+    sg = A.segs[g];
+    if (sg.stream < H->max_streams && !(sg.residue_off & 3)) {  // (otherwise the layout kernel flagged the segment)
+      si = A.sinfo[g];
+      cls = __builtin_amdgcn_readfirstlane((uint32_t)A.run_cls[(size_t)g * A.runs_per_seg + run]);
+    }
+  }
   const uint32_t qa = run * A.R;
   const uint32_t qb = min(sg.num_packets, qa + A.R);
-  const SegInfo si = A.sinfo[g];
-  uint32_t cls = run < A.runs_per_seg ? (uint32_t)A.run_cls[(size_t)g * A.runs_per_seg + run] : 0xFFu;
-  cls = __builtin_amdgcn_readfirstlane(cls);
   const bool active = (cls == 1u && (A.fused_ok & 1u)) || (cls == 2u && (A.fused_ok & 2u));
   if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing in this workgroup: leave before staging the tables
   {
@@ -872,8 +882,10 @@ static inline uint32_t fused_pick_run_len(const FusedTables& ft, uint32_t S, uin
 }
 
 static inline hipError_t fused_launch(const ConstHeader& H, const FusedTables& ft, FusedArgs a, uint32_t max_seg_packets, hipStream_t s) {
-  const uint32_t units = ((max_seg_packets + a.R - 1) / a.R) * H.channels;
-  dim3 grid((units + FUSED_WAVES - 1) / FUSED_WAVES, a.S);
+  const uint64_t units = (uint64_t)a.S * a.runs_per_seg * H.channels;  // a.runs_per_seg = ceil(max_seg_packets / R)
+  (void)max_seg_packets;
+  if (units == 0 || units > 0x7FFFFFF8ull) return hipErrorInvalidValue;
+  dim3 grid((uint32_t)((units + FUSED_WAVES - 1) / FUSED_WAVES));
   const char* xl = getenv("VSYN_EXTRA_LDS");  // experiment knob: extra dynamic LDS lowers the occupancy
   const size_t dyn = xl ? (size_t)atoi(xl) : 0;
   a.coupling_mode = (uint32_t)ft.coupling_mode;

@@ -82,6 +82,7 @@ SHAPES = [  # (channels, bs0, bs1, pattern, streams, packets)
     (3, 128, 1024, "mixed", 3, 21),
     (2, 512, 512, "short", 2, 8),
     (2, 2048, 4096, "mixed", 2, 12),
+    (2, 256, 2048, "mixed", 2, 2300),  # segments beyond 2048 packets: the layout kernel's wide block
 ]
 
 
