@@ -523,8 +523,13 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged;
   hipStream_t ps = overlap_pre ? h->pre : s;
   if (h->main_done_valid[wb]) HIPCHK(hipStreamWaitEvent(ps, h->ev_main_done[wb], 0));
-  vsyn_layout_kernel<<<S, 256, 0, ps>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len,
-                                        h->d_status, R, force_staged ? 0u : h->fused_mask, list, cnt, cnt_next, segmap, h->ws_runcls[wb].p, runs_per_seg);
+  {
+    const uint32_t lt = max_seg_packets <= LAYOUT_SHORT_PACKETS ? LAYOUT_THREADS_SHORT : LAYOUT_THREADS;
+    const uint32_t bitmap_packets = std::min<uint32_t>(max_seg_packets, LAYOUT_BITMAP_PACKETS);
+    vsyn_layout_kernel<<<S, lt, layout_lds_bytes(lt, bitmap_packets), ps>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len,
+                                                                          h->d_status, R, force_staged ? 0u : h->fused_mask, list, cnt, cnt_next, segmap,
+                                                                          h->ws_runcls[wb].p, runs_per_seg, bitmap_packets);
+  }
   {
     const uint32_t rows = P * C;
     vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,

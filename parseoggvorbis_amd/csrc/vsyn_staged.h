@@ -69,15 +69,24 @@ __device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_
   return 0;
 }
 
-__global__ void __launch_bounds__(256)
+// Block size LAYOUT_THREADS, or one wavefront per segment (LAYOUT_THREADS_SHORT) when no segment of the batch has more than
+// LAYOUT_SHORT_PACKETS packets: a batch of thousands of short streams would otherwise put four nearly idle waves per segment
+// on the chip, next to the synthesis kernel. Dynamic LDS: layout_lds_bytes().
+#define LAYOUT_THREADS 256
+#define LAYOUT_THREADS_SHORT 64
+#define LAYOUT_SHORT_PACKETS 512u
+static inline __host__ __device__ size_t layout_lds_bytes(uint32_t threads, uint32_t bitmap_packets) {
+  return (size_t)threads * (sizeof(AbsScan) + sizeof(uint64_t)) + (size_t)((bitmap_packets + 31u) / 32u) * 4u + 16u;
+}
+__global__ void __launch_bounds__(LAYOUT_THREADS)
 vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet* __restrict__ pk, uint32_t S,
                    const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
                    SegInfo* __restrict__ sinfo, StreamState* __restrict__ state, uint32_t* __restrict__ emit_len,
                    DevStatus* __restrict__ status, uint32_t R, uint32_t fused_ok, uint32_t* __restrict__ staged_list,
                    uint32_t* __restrict__ staged_count, uint32_t* __restrict__ next_count, uint32_t* __restrict__ seg_of_pkt,
-                   uint8_t* __restrict__ run_cls, uint32_t runs_per_seg) {
+                   uint8_t* __restrict__ run_cls, uint32_t runs_per_seg, uint32_t bitmap_packets) {
   const ConstHeader* H = hdr_of(cb);
-  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  const uint32_t g = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
   if (g >= S) return;
   if (g == 0 && t == 0) *next_count = 0;  // the other submit parity's list counter (no memset node needed)
   const vsyn_segment sg = segs[g];
@@ -87,10 +96,10 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       raise_status(status, VSYN_ST_BAD_SEGMENT, sg.first_packet < P ? sg.first_packet : 0);
       sinfo[g] = SegInfo{0, 0, 0, 0};
     }
-    for (uint32_t r = t; r < runs_per_seg; r += 256) run_cls[(size_t)g * runs_per_seg + r] = 0xFFu;
+    for (uint32_t r = t; r < runs_per_seg; r += NT) run_cls[(size_t)g * runs_per_seg + r] = 0xFFu;
     // mark every packet we may safely touch as bad so later kernels skip it
     if ((uint64_t)sg.first_packet + sg.num_packets <= P)
-      for (uint32_t q = t; q < sg.num_packets; q += 256) {
+      for (uint32_t q = t; q < sg.num_packets; q += NT) {
         PktInfo pi = {};
         pi.bad = 1;
         pi.n = (uint16_t)H->bs[0];
@@ -104,16 +113,17 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   const uint32_t carry_n = (!reset && st0.has_prev) ? st0.prev_n : 0;
   const int64_t abs0 = reset ? 0 : (int64_t)st0.abs_total_pos;
 
-  __shared__ AbsScan s_abs[256];
-  __shared__ uint64_t s_res[256];
-  __shared__ uint32_t s_longbits[LAYOUT_BITMAP_PACKETS / 32u];
-  const bool use_bits = num <= LAYOUT_BITMAP_PACKETS;
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // layout_lds_bytes(): scan arrays [NT], then the bitmap
+  AbsScan* s_abs = (AbsScan*)s_dyn;
+  uint64_t* s_res = (uint64_t*)(s_dyn + (size_t)NT * sizeof(AbsScan));
+  uint32_t* s_longbits = (uint32_t*)(s_dyn + (size_t)NT * (sizeof(AbsScan) + sizeof(uint64_t)));  // [min(max_seg, LAYOUT_BITMAP_PACKETS) / 32]
+  const bool use_bits = num <= bitmap_packets;  // (the launch sized the bitmap for the longest segment it was told about)
   if (use_bits)
-    for (uint32_t w = t; w < (num + 31u) / 32u; w += 256) s_longbits[w] = 0u;
+    for (uint32_t w = t; w < (num + 31u) / 32u; w += NT) s_longbits[w] = 0u;
   __shared__ int64_t s_abs_end;
   __shared__ uint32_t s_last_n;
 
-  const uint32_t per = (num + 255) / 256;
+  const uint32_t per = (num + NT - 1) / NT;
   const uint32_t qb = min(num, t * per), qe = min(num, qb + per);
   const vsyn_packet* spk = pk + sg.first_packet;
 
@@ -160,7 +170,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
         if (base + j < qe) step_a(kq[j]);
     }
   }
-  // exclusive scan over the 256 thread aggregates: wave-level shuffles, then the 4 wave totals through LDS
+  // exclusive scan over the thread aggregates: wave-level shuffles, then the wave totals through LDS
   {
     const uint32_t lane = t & 63u, wv = t >> 6;
     AbsScan inc = agg;
@@ -286,7 +296,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   // appended to the staged work list (entry = packet index | emit << 31; halo packets carry emit = 0).
   {
     const uint32_t nruns = (num + R - 1) / R;
-    for (uint32_t r = t; r < runs_per_seg; r += 256) {
+    for (uint32_t r = t; r < runs_per_seg; r += NT) {
       const uint32_t qa = r * R, qb2 = min(num, qa + R);
       const uint32_t cls = r >= nruns ? 0xFFu  // 0xFF: no such run
                            : use_bits ? run_class_bits(s_longbits, qa, qb2, carry_n, fused_ok)
