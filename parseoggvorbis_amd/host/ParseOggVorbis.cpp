@@ -204,6 +204,43 @@ uint32_t VorbisCodebook::decodeScalar(BitReader& reader) const {
   return 0xffffffffu;
 }
 
+// The same as `count` calls of decodeScalar, with the bit window held in a register between code words: one 64-bit load feeds
+// several table look-ups (the per-word reload and byte/bit bookkeeping was most of decodeScalar's dependent chain).
+uint32_t VorbisCodebook::decodeRun(BitReader& reader, uint32_t count, uint16_t* dst) const {
+  uint32_t worst = 0, k = 0;
+  const uint32_t* const fast = fast_.data();
+  while (k < count) {
+    if (reader.byte_ + 16 <= reader.len_) {
+      uint64_t w;
+      memcpy(&w, reader.p_ + reader.byte_, 8);
+      w >>= reader.bit_;
+      int avail = 64 - reader.bit_, used = 0;
+      bool slow = false;
+      while (k < count && avail - used >= kFastBits) {
+        const uint32_t e = fast[w & ((1u << kFastBits) - 1u)];
+        if (!e) {  // longer than the table covers (or not a code word): the tree walk decides
+          slow = true;
+          break;
+        }
+        const int len = (int)(e & 0xffu);
+        w >>= len;
+        used += len;
+        const uint32_t v = e >> 8;
+        worst = v > worst ? v : worst;
+        dst[k++] = (uint16_t)v;
+      }
+      const size_t pos = (size_t)reader.bit_ + (size_t)used;
+      reader.byte_ += pos >> 3;
+      reader.bit_ = (int)(pos & 7);
+      if (!slow) continue;
+    }
+    const uint32_t v = decodeScalar(reader);
+    worst = v > worst ? v : worst;
+    dst[k++] = (uint16_t)v;
+  }
+  return worst;
+}
+
 const float* VorbisCodebook::decodeVector(BitReader& reader) const {
   const uint32_t idx = decodeScalar(reader);
   if (!lookup_type_ || idx >= num_entries_) return nullptr;
@@ -432,12 +469,7 @@ OkOrError VorbisResidue::decode_entries(BitReader& reader, const std::vector<Vor
           const size_t at = entries_out.size();
           entries_out.resize(at + count);
           uint16_t* dst = &entries_out[at];
-          uint32_t worst = 0;
-          for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t e = vq.decodeScalar(reader);
-            worst = e > worst ? e : worst;
-            dst[k] = (uint16_t)e;
-          }
+          const uint32_t worst = vq.decodeRun(reader, count, dst);
           CHECK(worst < vq.num_entries_);  // (0xffffffff = no such code word)
         }
       }

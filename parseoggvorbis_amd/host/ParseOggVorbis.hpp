@@ -62,6 +62,9 @@ struct VorbisCodebook {  // Vorbis I 3.2.1
 
   OkOrError parse(BitReader& reader);
   uint32_t decodeScalar(BitReader& reader) const;
+  // `count` code words in a row into dst (entry numbers are < 65536 for VQ use); returns the largest value decodeScalar would
+  // have returned (0xffffffff: no such code word)
+  uint32_t decodeRun(BitReader& reader, uint32_t count, uint16_t* dst) const;
   const float* decodeVector(BitReader& reader) const;  // dimensions_ floats, or nullptr (no VQ table / bad entry)
 };
 
