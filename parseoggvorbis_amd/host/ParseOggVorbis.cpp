@@ -435,7 +435,10 @@ OkOrError VorbisResidue::decode_entries(BitReader& reader, const std::vector<Vor
                                         std::vector<uint16_t>& entries_out, int type_override) const {
   const int type = type_override >= 0 ? type_override : (int)this->type;
   CHECK(num_channel > 0 && channel_used.size() == num_channel);
-  if (type == 2) return decode_entries(reader, codebooks, 1, std::vector<bool>{true}, num_channel * decode_len, cls_out, entries_out, 1);
+  if (type == 2) {
+    static const std::vector<bool> one_used{true};
+    return decode_entries(reader, codebooks, 1, one_used, num_channel * decode_len, cls_out, entries_out, 1);
+  }
   const uint32_t lim_begin = std::min(begin, decode_len), lim_end = std::min(end, decode_len);
   CHECK(lim_begin <= lim_end);
   const VorbisCodebook& cbook = codebooks[classbook];
@@ -444,8 +447,12 @@ OkOrError VorbisResidue::decode_entries(BitReader& reader, const std::vector<Vor
   if (!n_to_read) return OkOrError();
   const uint32_t parts = n_to_read / partition_size;
   const uint32_t per_ch = parts + cw;
-  std::vector<uint8_t> cls((size_t)num_channel * per_ch, 0);
+  static thread_local std::vector<uint8_t> cls;  // (scratch: one decoder per thread, Callbacks.h:16-21)
+  cls.assign((size_t)num_channel * per_ch, 0);
+  uint32_t pass_mask = 0;  // passes in which some class has a codebook: the others read nothing and are skipped whole
+  for (uint32_t x : cascades) pass_mask |= x;
   for (int pass = 0; pass < 8; ++pass) {
+    if (pass > 0 && !((pass_mask >> pass) & 1u)) continue;
     uint32_t pc = 0;
     while (pc < parts) {
       if (pass == 0)
