@@ -267,6 +267,13 @@ int vsyn_pcm_interleave_device(vsyn_handle* h, int format, const float* d_pcm, u
                                void* d_out, uint64_t out_stride_frames, uint32_t* d_frames,
                                void* hip_stream, const char** err);
 
+/* Per-(segment, channel) digest of the PCM of the MOST RECENT vsyn_submit_host / vsyn_submit_host_vq call on this handle:
+ * out[g * channels + c] = sum of |x| over segment g's emitted frames of channel c, accumulated in double in a fixed order (the
+ * same PCM always gives the same bits). Computed on the device from the PCM still resident there, so that a corpus decoder
+ * can tell that replicas agree — the reference's harness compares decoders sample by sample, compare-debug-out.py:524-542 —
+ * without another pass over the PCM on the host. `out` holds S * channels doubles of the last submit. Synchronous. */
+int vsyn_pcm_abs_sum_host(vsyn_handle* h, double* out, const char** err);
+
 /* Page-locked host memory for the buffers handed to vsyn_submit_host (direct DMA instead of the runtime's staging copies;
  * what a host decoder that batches at corpus scale wants). Pageable memory is accepted by vsyn_submit_host as well. */
 int vsyn_host_alloc(size_t bytes, void** out, const char** err);

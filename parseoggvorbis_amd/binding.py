@@ -173,7 +173,7 @@ _SYMBOLS = [
     "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels",
     "vsyn_const_block_bytes", "vsyn_submit_device", "vsyn_submit_host", "vsyn_sync_status", "vsyn_reset_streams",
     "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device", "vsyn_host_alloc", "vsyn_host_free",
-    "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq", "vsyn_pcm_interleave_device",
+    "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq", "vsyn_pcm_interleave_device", "vsyn_pcm_abs_sum_host",
 ]
 
 
@@ -225,6 +225,7 @@ def load():
     lib.vsyn_submit_host_vq.argtypes = [vp, u32, vp, u32, vp, vp, C.POINTER(VqBatch), vp, C.c_size_t, vp, u64, vp,
                                         C.POINTER(Taps), u32, C.POINTER(Status), cpp]
     lib.vsyn_pcm_interleave_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, vp, vp, cpp]
+    lib.vsyn_pcm_abs_sum_host.argtypes = [vp, C.POINTER(C.c_double), cpp]
     lib.vsyn_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp), cpp]
     lib.vsyn_host_free.argtypes = [vp]
     lib.vsyn_host_free.restype = None
@@ -355,6 +356,15 @@ class Synth:
                                                  C.byref(err))
         if rc != VSYN_OK:
             raise VsynError(rc, (err.value or b"").decode())
+
+    def pcm_abs_sum_host(self, num_segments):
+        """Per-(segment, channel) sum |x| of the PCM of the most recent submit_host*, computed on the device -> [S][C] float64."""
+        out = np.zeros((num_segments, self.channels), np.float64)
+        err = C.c_char_p()
+        rc = self.lib.vsyn_pcm_abs_sum_host(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
+        return out
 
     def sync_status(self, stream=None):
         st, err = Status(), C.c_char_p()

@@ -128,6 +128,8 @@ struct vsyn_handle {
   DevBuf<float> st_res, st_pcm, st_env, st_blk;
   DevBuf<uint16_t> st_curve;
   DevBuf<uint32_t> st_emit;
+  DevBuf<double> st_sum;               // vsyn_pcm_abs_sum_host
+  uint64_t last_host_plane = 0;        // plane_stride of the most recent vsyn_submit_host* (0: none yet)
   // profiling
   bool profile = false;
   int profile_which = 1;  // 1 / 2: the fused kernel (steady / mixed workloads: same kernel), 3: residue VQ kernel
@@ -744,6 +746,7 @@ static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packe
   int rc = submit_device_impl(h, P, h->st_pk.p, S, h->st_seg.p, max_seg, h->st_ys.p, vq ? &dvq : nullptr, h->st_res.p, h->st_pcm.p, plane_stride,
                               h->st_emit.p, any_tap ? &dt : nullptr, flags & ~VSYN_SUBMIT_INPUTS_READY, hs, err);
   if (rc) return rc;
+  h->last_host_plane = plane_stride;
   if (vq && residue_out) HIPCHK(hipMemcpyAsync(residue_out, h->st_res.p, sizeof(float) * residue_floats, hipMemcpyDeviceToHost, hs));
   // results are queued behind the kernels before the one host wait
   HIPCHK(hipMemcpyAsync(pcm, h->st_pcm.p, sizeof(float) * pcm_n, hipMemcpyDeviceToHost, hs));
@@ -792,6 +795,22 @@ int vsyn_pcm_interleave_device(vsyn_handle* h, int format, const float* d_pcm, u
   else
     vsyn_pcm_interleave_kernel<VSYN_PCM_F32><<<grid, 256, 0, s>>>(h->d_const, si, h->last_S, d_pcm, plane_stride, d_out, out_stride_frames, d_frames);
   HIPCHK(hipGetLastError());
+  return VSYN_OK;
+}
+
+int vsyn_pcm_abs_sum_host(vsyn_handle* h, double* out, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  if (!out) return fail(err, VSYN_ERR_INVALID, "out is NULL");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->last_S == 0 || h->last_host_plane == 0) return fail(err, VSYN_ERR_INVALID, "no vsyn_submit_host on this handle yet");
+  HIPCHK(hipSetDevice(h->device));
+  const uint32_t units = h->last_S * h->H.channels;
+  HIPCHK(h->st_sum.ensure(units));
+  vsyn_pcm_abs_sum_kernel<<<units, 256, 0, h->host_stream>>>(h->d_const, h->ws_seg[h->last_wb].p, h->last_S, h->st_pcm.p, h->last_host_plane,
+                                                              h->st_sum.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, h->st_sum.p, sizeof(double) * units, hipMemcpyDeviceToHost, h->host_stream));
+  HIPCHK(hipStreamSynchronize(h->host_stream));
   return VSYN_OK;
 }
 

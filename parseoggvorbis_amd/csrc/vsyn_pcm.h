@@ -55,3 +55,30 @@ __global__ void __launch_bounds__(256) vsyn_pcm_interleave_kernel(const uint8_t*
     }
 }
 
+
+// Per-(segment, channel) digest: sum of |x| over the segment's emitted frames, in double, in a fixed order (thread t adds
+// samples t, t + 256, ...; then a fixed LDS tree): the same PCM always gives the same bits, whatever else runs on the GPU.
+__global__ void __launch_bounds__(256) vsyn_pcm_abs_sum_kernel(const uint8_t* __restrict__ cb, const SegInfo* __restrict__ sinfo, uint32_t S,
+                                                               const float* __restrict__ pcm, uint64_t plane_stride, double* __restrict__ out) {
+  __shared__ double s_part[256];
+  const uint32_t C = hdr_of(cb)->channels, u = blockIdx.x, g = u / C, t = threadIdx.x;
+  if (g >= S) return;
+  const uint32_t frames = (uint32_t)min((uint64_t)sinfo[g].total_emit, plane_stride);
+  const float* x = pcm + (size_t)u * plane_stride;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // four chains per thread: the adds of one chain are dependent
+  uint32_t i = t;
+  for (; i + 768u < frames; i += 1024u) {
+    a0 += (double)fabsf(x[i]);
+    a1 += (double)fabsf(x[i + 256u]);
+    a2 += (double)fabsf(x[i + 512u]);
+    a3 += (double)fabsf(x[i + 768u]);
+  }
+  for (; i < frames; i += 256u) a0 += (double)fabsf(x[i]);
+  s_part[t] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  for (uint32_t d = 128; d; d >>= 1) {
+    if (t < d) s_part[t] += s_part[t + d];
+    __syncthreads();
+  }
+  if (t == 0) out[u] = s_part[0];
+}

@@ -296,6 +296,14 @@ struct Feeder {
     } else {
       rc = vsyn_submit_host(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, g.residue.p, rfloats, g.pcm.p, plane, g.emit.p, nullptr, 0, &st, &err);
     }
+    // per-(file, channel) digests from the device, where the PCM still is (a host pass over it cost more than the decode's GPU calls)
+    std::vector<double> digest;
+    if (opts.checksum && rc == VSYN_OK) {
+      digest.resize((size_t)S * C);
+      const char* derr = nullptr;
+      if (vsyn_pcm_abs_sum_host(g.handle, digest.data(), &derr) != VSYN_OK)
+        return OkOrError(std::string("GPU synthesis layer: ") + (derr ? derr : "digest failed"));
+    }
     double t2 = now_s();
     stats.gpu_call_s += t2 - t1;
     stats.submits++;
@@ -331,7 +339,7 @@ struct Feeder {
         for (uint32_t c = 0; c < C; ++c) {
           const float* x = &g.pcm[((size_t)s * C + c) * plane];
           chans[c] = DataRange<const float>(x, frames);
-          if (opts.checksum) acc += abs_sum_f32(x, frames);
+          if (opts.checksum) acc += digest.empty() ? abs_sum_f32(x, frames) : digest[(size_t)s * C + c];
         }
         out.frames = frames;
         out.abs_sum = acc;

@@ -56,7 +56,7 @@ struct CorpusOptions {
   int device = 0;                   // HIP ordinal
   bool entropy_only = false;        // diagnostic: run the workers only and count packets (no GPU call, no PCM, frames stay 0)
   bool share_setups = true;         // parse byte-identical setup headers once per run (SetupCache)
-  bool checksum = true;             // fill CorpusFileResult::abs_sum (one pass over the PCM on the feeder thread)
+  bool checksum = true;             // fill CorpusFileResult::abs_sum (digest computed on the device, vsyn_pcm_abs_sum_host)
 };
 
 struct CorpusStats {

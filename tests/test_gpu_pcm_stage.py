@@ -58,3 +58,26 @@ def test_pcm_stage_matches_oracle(channels, pattern):
     # the half-way cases round to even, the edges clamp
     got = s16[0, :special.numel(), 0].tolist()
     assert got[:8] == [0, 2, 2, 0, -2, -2, 32767, -32768] and got[9:14] == [32767, -32768, 32766, 32767, -32768]
+
+
+def test_pcm_abs_sum_host_matches_numpy():
+    """The per-(segment, channel) digest of the last host submit (what the corpus decoder reports per file): equals the sum of |x|
+    over the emitted frames to double rounding, is reproducible bit for bit, and ignores what lies beyond the emitted frames."""
+    import numpy as np
+    from parseoggvorbis_amd import binding
+    from tests.workloads import fixture_like_spec, synth_batch
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, 5, 23, "mixed", seed=4, granule_last=True)
+    gpu = binding.Synth(spec, max_streams=5)
+    with pytest.raises(binding.VsynError):
+        gpu.pcm_abs_sum_host(5)  # nothing submitted yet
+    r = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert r["rc"] == 0
+    d1 = gpu.pcm_abs_sum_host(5)
+    per = len(b["packets"]) // 5
+    for s in range(5):
+        frames = int(r["emit_len"][s * per:(s + 1) * per].sum())
+        want = np.abs(r["pcm"][s][:, :frames].astype(np.float64)).sum(axis=1)
+        assert np.allclose(d1[s], want, rtol=1e-12, atol=0)
+    r2 = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert r2["rc"] == 0 and np.array_equal(gpu.pcm_abs_sum_host(5).view(np.uint64), d1.view(np.uint64))
