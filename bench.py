@@ -95,8 +95,9 @@ def run_config5(args, rank, world, local, device):
     want_frames = int(gold["pcm"].shape[-1])  # the reference decoder's total for this file (granule-derived)
     n = args.files_per_gpu
     cores = os.cpu_count() or 16
-    threads = args.host_threads or max(2, min(16, cores // max(1, world)))
-    feeders = 4 if threads >= 12 else 2
+    share = max(2, min(16, cores // max(1, world)))   # this rank's cores: one entropy worker each; the feeders mostly wait on the GPU
+    feeders = 3 if share >= 12 else (2 if share >= 6 else 1)
+    threads = args.host_threads or share
     datas = (C.c_char_p * n)(*([blob] * n))
     lens = (C.c_size_t * n)(*([len(blob)] * n))
     frames = (C.c_uint64 * n)()
