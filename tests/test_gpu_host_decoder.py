@@ -218,3 +218,26 @@ def test_bench_config5_line():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["config"]["packets_per_gpu"] == 96 * 94 and j["replicas_bit_identical"] and j["value"] > 0
+
+
+@pytest.mark.parametrize("vq", ["1", "0"])
+def test_synthetic_streams_pcm_matches_reference(vq, monkeypatch):
+    """The 16 synthetic streams of tests/golden (oracle/make_synth_ogg.py: setups the real fixtures do not have, golden PCM from
+    the reference decoder) end to end through the corpus decoder — host entropy half, device VQ stage or float residue,
+    synthesis kernels (most of these shapes take the staged kernels: 3 channels, other block sizes, chained couplings).
+    Frame counts equal the reference's; PCM within 4e-6 of the stream's peak (the reference's own harness allows 1e-5 at
+    |pcm| <= 1, compare-debug-out.py:90; these streams peak between 0.2 and 160)."""
+    monkeypatch.setenv("PARSEOGGVORBIS_VQ", vq)
+    names = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("synth_") and f.endswith(".ogg"))
+    assert len(names) >= 16
+    gold = [np.load(os.path.join(GOLDEN, n + ".npz")) for n in names]
+    blobs = [open(os.path.join(GOLDEN, n + ".ogg"), "rb").read() for n in names]
+    chans = [int(z["channels"]) for z in gold]
+    frames, sums, ok, pcm, stats = _run_corpus(blobs, chans, threads=3, feeders=2, files_per_submit=5, cap=16384)
+    for i, z in enumerate(gold):
+        want = z["pcm"]
+        assert ok[i], names[i]
+        assert frames[i] == want.shape[1], (names[i], frames[i], want.shape)
+        peak = float(np.abs(want).max())
+        err = float(np.abs(pcm[i][:, :frames[i]] - want).max())
+        assert err <= 4e-6 * max(peak, 1.0), (names[i], err, peak)

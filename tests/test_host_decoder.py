@@ -243,3 +243,55 @@ def test_mutated_files_never_crash_the_front_end(built, tmp_path):
     assert r.returncode in (0, 1), (r.returncode, r.stderr[-500:])  # 1: some files failed (expected); negative: a crash
     out = json.loads(r.stdout)
     assert out["files"] == 48 and 0 < out["failed"] <= 48
+
+
+SYNTH = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("synth_") and f.endswith(".ogg"))
+
+
+@pytest.mark.parametrize("name", SYNTH)
+def test_synthetic_streams_entropy_half_matches_reference(probe, name, tmp_path):
+    """Streams written by oracle/make_synth_ogg.py from the Vorbis I specification — setups the two real fixtures do not have:
+    1-3 channels, other block sizes, floor multipliers / post counts / subclass books, residue formats 0 / 1 / 2, vector lengths
+    that are not powers of two, lookup types 1 and 2, sequence_p, sparse and ordered codebooks, two submaps, several coupling
+    steps — with the REFERENCE decoder's hooks on them as golden vectors. The host's entropy half must reproduce the
+    reference's 'floor1 ys' and 'after_residue' exactly, both as floats (PARSEOGGVORBIS_VQ=0) and as entry numbers pushed
+    through the oracle's accumulate stage (VQ mode)."""
+    from oracle import oracle_binding as ob
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = str(tmp_path / "e.bin")
+    for vq in ("0", "1"):
+        r = subprocess.run([probe, os.path.join(GOLDEN, name + ".ogg"), out], capture_output=True, text=True,
+                           env=dict(os.environ, PARSEOGGVORBIS_VQ=vq))
+        assert r.returncode == 0, r.stderr
+        d = read_entropy_dump(out)
+        Cn = d["channels"]
+        assert d["P"] == int(z["packets"]) and Cn == int(z["channels"])
+        assert (d["blocksize0"], d["blocksize1"]) == (int(z["blocksize0"]), int(z["blocksize1"]))
+        off = 0
+        for ln, where in zip(z["ys_len"], z["ys_where"]):
+            p, c = divmod(int(where), 1000)
+            assert np.array_equal(d["ys"][p, c, :ln].astype(np.uint32), z["ys"][off:off + ln]), (p, c)
+            off += ln
+        if vq == "0":
+            assert "vq_spec" not in d
+            assert np.array_equal(d["residue"].view(np.uint32), z["residue"].view(np.uint32))
+            continue
+        assert d["residue"].size == 0 and d["residue_floats"] == z["residue"].size
+        roff = 0
+        for p in range(d["P"]):
+            mode = int(d["packets"]["mode"][p])
+            mapping = int(z["mode_mapping"][mode])
+            n2 = (d["blocksize1"] if mode == 1 else d["blocksize0"]) // 2
+            used = int(d["packets"]["floor_used"][p])
+            for mag, ang in z["coupling_m%d" % mapping]:  # nonzero propagate, hpp:1174-1180
+                if (used >> int(mag)) & 1 or (used >> int(ang)) & 1:
+                    used |= (1 << int(mag)) | (1 << int(ang))
+            vp = d["vq_packets"][p]
+            c0 = int(vp["cls_off"])
+            c1 = int(d["vq_packets"][p + 1]["cls_off"]) if p + 1 < d["P"] else d["cls"].size
+            e0, ne = int(vp["entry_off"]), int(vp["num_entries"])
+            rc, res = ob.residue_vq(d["vq_spec"], mapping, Cn, n2, used, d["cls"][c0:c1], d["entries"][e0:e0 + ne])
+            assert rc == 0, (p, rc)
+            assert np.array_equal(res.view(np.uint32), z["residue"][roff:roff + Cn * n2].view(np.uint32)), p
+            roff += Cn * n2
+        assert roff == z["residue"].size
