@@ -186,8 +186,8 @@ class Setup:
 
 def make_setup(rng):
     s = Setup()
-    s.channels = int(rng.choice([1, 2, 2, 2, 3]))
-    s.bs0, s.bs1 = [(64, 256), (128, 1024), (256, 2048), (256, 2048), (512, 512), (64, 64), (128, 512)][int(rng.integers(0, 7))]
+    s.channels = int(rng.choice([1, 2, 2, 2, 3, 3, 4, 6]))
+    s.bs0, s.bs1 = [(64, 256), (128, 1024), (256, 2048), (256, 2048), (512, 512), (64, 64), (128, 512), (256, 2048), (512, 4096)][int(rng.integers(0, 9))]
     s.rate = 44100
     books = []
 
@@ -275,7 +275,10 @@ def make_setup(rng):
 
     s.residues = []
     s.mappings = []
-    for blk, n in enumerate((s.bs0, s.bs1)):
+    blocks = [(0, s.bs0), (1, s.bs1)]
+    if rng.random() < 0.35:
+        blocks.append((1, s.bs1))  # a second long-block mode with its own mapping (other coupling / submaps / residue)
+    for blk, n in blocks:
         m = Setup()
         m.submaps = 2 if (s.channels >= 2 and rng.random() < 0.3) else 1
         m.mux = [0] * s.channels
@@ -284,7 +287,7 @@ def make_setup(rng):
                 m.mux = [int(rng.integers(0, m.submaps)) for _ in range(s.channels)]
         m.coupling = []
         if s.channels >= 2 and rng.random() < 0.7:
-            steps = 1 if s.channels == 2 else int(rng.integers(1, 3))
+            steps = 1 if s.channels == 2 else int(rng.integers(1, min(4, s.channels)))
             for _ in range(steps):
                 a, b = rng.choice(s.channels, 2, replace=False).tolist()
                 m.coupling.append((int(a), int(b)))
@@ -294,7 +297,7 @@ def make_setup(rng):
             s.residues.append(make_residue(n, max(1, nch)))
             m.sub.append((blk, len(s.residues) - 1))  # (floor, residue)
         s.mappings.append(m)
-    s.modes = [(0, 0), (1, 1)]  # (blockflag, mapping)
+    s.modes = [(blk, k) for k, (blk, _) in enumerate(blocks)]  # (blockflag, mapping)
     s.books = books
     return s
 
@@ -523,7 +526,9 @@ def make_stream(seed):
         lng = flags[q]
         prev_long = flags[q - 1] if q else 1
         next_long = flags[q + 1] if q + 1 < npk else 1
-        pkt = write_audio(s, rng, lng, prev_long, next_long)
+        long_modes = [k for k, (bf, _) in enumerate(s.modes) if bf]
+        mode = long_modes[int(rng.integers(0, len(long_modes)))] if lng else 0
+        pkt = write_audio(s, rng, mode, prev_long, next_long)
         assert len(pkt) < 255 * 200
         n = s.bs1 if lng else s.bs0
         pos += (prev_n // 4 + n // 4) if prev_n else 0
@@ -589,13 +594,15 @@ def main():
         path = os.path.join(OUT, "synth_%02d.ogg" % made)
         open(path, "wb").write(data)
         vec, why = reference_vectors(path)
-        if vec is None or vec["pcm"].shape[1] == 0 or not np.isfinite(vec["pcm"]).all() or np.abs(vec["pcm"]).max() > 1e4:
-            print("seed %d rejected: %s" % (seed, (why or "empty / non-finite / huge pcm").strip().replace("\n", " | ")[-200:]))
+        too_big = vec is not None and vec["pcm"].nbytes > int(os.environ.get("SYNTH_MAX_PCM_BYTES", "1000000000"))
+        if vec is None or too_big or vec["pcm"].shape[1] == 0 or not np.isfinite(vec["pcm"]).all() or np.abs(vec["pcm"]).max() > 1e4:
+            print("seed %d skipped: %s" % (seed, (why or "empty / non-finite / huge pcm / over the size limit").strip().replace("\n", " | ")[-200:]))
             os.remove(path)
             seed += 1
             continue
         # what a test needs to redo the nonzero propagate (4.3.3) per packet: mode -> mapping -> coupling steps
-        extra = dict(blocksize0=np.int32(s.bs0), blocksize1=np.int32(s.bs1), mode_mapping=np.asarray([m for _, m in s.modes], np.int32))
+        extra = dict(blocksize0=np.int32(s.bs0), blocksize1=np.int32(s.bs1), mode_mapping=np.asarray([m for _, m in s.modes], np.int32),
+                     mode_blockflag=np.asarray([bf for bf, _ in s.modes], np.int32))
         for k, mp in enumerate(s.mappings):
             extra["coupling_m%d" % k] = np.asarray(mp.coupling, np.int32).reshape(-1, 2)
         np.savez_compressed(os.path.join(OUT, "synth_%02d.npz" % made), seed=np.int32(seed), **vec, **extra)

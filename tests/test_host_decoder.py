@@ -281,7 +281,7 @@ def test_synthetic_streams_entropy_half_matches_reference(probe, name, tmp_path)
         for p in range(d["P"]):
             mode = int(d["packets"]["mode"][p])
             mapping = int(z["mode_mapping"][mode])
-            n2 = (d["blocksize1"] if mode == 1 else d["blocksize0"]) // 2
+            n2 = (d["blocksize1"] if int(z["mode_blockflag"][mode]) else d["blocksize0"]) // 2
             used = int(d["packets"]["floor_used"][p])
             for mag, ang in z["coupling_m%d" % mapping]:  # nonzero propagate, hpp:1174-1180
                 if (used >> int(mag)) & 1 or (used >> int(ang)) & 1:
