@@ -605,6 +605,11 @@ def main():
                      mode_blockflag=np.asarray([bf for bf, _ in s.modes], np.int32))
         for k, mp in enumerate(s.mappings):
             extra["coupling_m%d" % k] = np.asarray(mp.coupling, np.int32).reshape(-1, 2)
+            extra["chfloor_m%d" % k] = np.asarray([mp.sub[mp.mux[c]][0] for c in range(s.channels)], np.int32)
+        for k, f in enumerate(s.floors):  # the synthesis-side setup (what vsyn_setup / the oracle take)
+            extra["floor%d_mult" % k] = np.int32(f.multiplier)
+            extra["floor%d_xs" % k] = np.asarray(f.xs, np.int32)
+        extra["num_floors"] = np.int32(len(s.floors))
         np.savez_compressed(os.path.join(OUT, "synth_%02d.npz" % made), seed=np.int32(seed), **vec, **extra)
         print("synth_%02d: seed %d, %d ch, blocks %d/%d, %d packets, %d frames, |pcm| <= %.3g, %d bytes"
               % (made, seed, s.channels, s.bs0, s.bs1, npk, vec["pcm"].shape[1], float(np.abs(vec["pcm"]).max()), len(data)))

@@ -89,3 +89,45 @@ def test_error_flags():
     assert r["rc"] == 4 and r["flags"] & 3 and r["first_bad"] == 7
     r = orc.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], 100)
     assert r["flags"] & 8  # plane overflow
+
+
+def _synth_names():
+    import os
+    from tests.workloads import GOLDEN
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("synth_") and f.endswith(".ogg"))
+
+
+@pytest.mark.parametrize("name", _synth_names())
+def test_full_path_matches_reference_on_synthetic_streams(name, tmp_path_factory):
+    """The oracle's whole synthesis path (floor unwrap + curve, propagate, coupling chains, product, IMDCT of every block size,
+    windows, overlap, granule clipping) on the synthetic streams of oracle/make_synth_ogg.py — 2-6 channels, floor multipliers
+    1-4, up to three coupling steps, three modes, block sizes 64 ... 4096: bit-identical to the REFERENCE decoder's PCM.
+    Inputs are the host decoder's entropy output (tests/host_entropy_dump.cpp), itself checked against the reference's hooks
+    in tests/test_host_decoder.py."""
+    import os
+    import subprocess
+    from parseoggvorbis_amd.binding import SEGMENT_DTYPE, SetupSpec
+    from tests.workloads import GOLDEN, build_probe, read_entropy_dump
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    td = tmp_path_factory.mktemp("probe_" + name)
+    probe = build_probe(td)
+    out = os.path.join(td, "e.bin")
+    r = subprocess.run([probe, os.path.join(GOLDEN, name + ".ogg"), out], capture_output=True, text=True,
+                       env=dict(os.environ, PARSEOGGVORBIS_VQ="0"))
+    assert r.returncode == 0, r.stderr
+    d = read_entropy_dump(out)
+    C = int(z["channels"])
+    floors = [(int(z["floor%d_mult" % k]), [int(x) for x in z["floor%d_xs" % k]]) for k in range(int(z["num_floors"]))]
+    nmap = int(z["mode_mapping"].max()) + 1
+    mappings = [([(int(a), int(b)) for a, b in z["coupling_m%d" % k]], [int(f) for f in z["chfloor_m%d" % k]]) for k in range(nmap)]
+    modes = [(int(bf), int(mp)) for bf, mp in zip(z["mode_blockflag"], z["mode_mapping"])]
+    spec = SetupSpec(C, int(z["blocksize0"]), int(z["blocksize1"]), floors, mappings, modes)
+    seg = np.zeros(1, SEGMENT_DTYPE)
+    seg["num_packets"], seg["flags"] = d["P"], 1
+    total = z["pcm"].shape[1]
+    orc = ob.OracleSynth(spec, max_streams=1)
+    assert orc.ys_stride == d["ys_stride"]
+    res = orc.submit_host(d["packets"], seg, d["ys"], d["residue"], total + 8)
+    assert res["rc"] == 0 and res["flags"] == 0, res
+    assert int(res["emit_len"].sum()) == total
+    assert np.array_equal(bits(res["pcm"][0][:, :total]), bits(z["pcm"]))
