@@ -579,7 +579,17 @@ def reference_vectors(path):
         elif nm == "pcm":
             pcm[ch].append(v.astype(np.float32))
     pcm = np.stack([np.concatenate(p) if p else np.zeros(0, np.float32) for p in pcm])
-    return dict(channels=np.int32(C), packets=np.int32(packets), pcm=pcm,
+    # the whole hook stream in digest form — name, channel, length and (integers) a CRC of the values as int64 / (floats) sum
+    # and sum of magnitudes in double —, "pcm" entries left out (the chunking of PCM across calls may differ)
+    import zlib
+    hk = [(nm, ch, v) for nm, ch, v in entries if nm != "pcm"]
+    hook = dict(hook_names=np.asarray([nm.encode() for nm, _, _ in hk]), hook_ch=np.asarray([ch for _, ch, _ in hk], np.int16),
+                hook_len=np.asarray([len(v) for _, _, v in hk], np.int32),
+                hook_float=np.asarray([v.dtype.kind == "f" for _, _, v in hk], np.bool_),
+                hook_crc=np.asarray([0 if v.dtype.kind == "f" else zlib.crc32(v.astype(np.int64).tobytes()) for _, _, v in hk], np.uint32),
+                hook_sum=np.asarray([float(v.astype(np.float64).sum()) if v.dtype.kind == "f" else 0.0 for _, _, v in hk]),
+                hook_abs=np.asarray([float(np.abs(v.astype(np.float64)).sum()) if v.dtype.kind == "f" else 0.0 for _, _, v in hk]))
+    return dict(channels=np.int32(C), packets=np.int32(packets), pcm=pcm, **hook,
                 ys=np.concatenate(ys) if ys else np.zeros(0, np.uint32), ys_len=np.asarray(ys_len, np.int32),
                 ys_where=np.asarray(ys_ch, np.int32),  # packet * 1000 + channel of every "floor1 ys" entry
                 residue=np.concatenate(res) if res else np.zeros(0, np.float32), residue_len=np.asarray(res_len, np.int32)), ""

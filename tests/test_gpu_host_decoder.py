@@ -241,3 +241,39 @@ def test_synthetic_streams_pcm_matches_reference(vq, monkeypatch):
         peak = float(np.abs(want).max())
         err = float(np.abs(pcm[i][:, :frames[i]] - want).max())
         assert err <= 4e-6 * max(peak, 1.0), (names[i], err, peak)
+
+
+def _synth_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("synth_") and f.endswith(".ogg"))
+
+
+@pytest.mark.parametrize("name", _synth_names())
+def test_cli_dump_matches_reference_on_synthetic_streams(name, tmp_path):
+    """ours_hip.bin --debug_out on the synthetic streams: the SAME hook stream as the reference decoder's — every entry name,
+    channel and length in the same order (what tests/compare-debug-out.py of the reference walks, 154-198 / 380-401), integer
+    hooks equal (CRC over the values), float hooks equal to 1e-5 of their magnitude sums, PCM as in the corpus test."""
+    import zlib
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dump = str(tmp_path / "d.bin")
+    r = subprocess.run([CLI, "--in", os.path.join(GOLDEN, name + ".ogg"), "--debug_out", dump], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    header, entries = read_dump(dump)
+    Cn = int(z["channels"])
+    assert int(header["decoder-num-channels"][0]) == Cn
+    hk = [(nm, ch, v) for nm, ch, v, _ in entries if nm != "pcm"]
+    assert [nm.encode() for nm, _, _ in hk] == list(z["hook_names"])
+    assert [ch for _, ch, _ in hk] == list(z["hook_ch"])
+    assert [len(v) for _, _, v in hk] == list(z["hook_len"])
+    for i, (nm, ch, v) in enumerate(hk):
+        if z["hook_float"][i]:
+            assert v.dtype.kind == "f", (i, nm)
+            a = v.astype(np.float64)
+            tol = 1e-5 * (float(z["hook_abs"][i]) + 1e-30) + 1e-12
+            assert abs(float(a.sum()) - float(z["hook_sum"][i])) <= tol and abs(float(np.abs(a).sum()) - float(z["hook_abs"][i])) <= tol, (i, nm, ch)
+        else:
+            assert zlib.crc32(v.astype(np.int64).tobytes()) == int(z["hook_crc"][i]), (i, nm, ch)
+    pcm = [np.concatenate([v for nm, ch, v, _ in entries if nm == "pcm" and ch == c] or [np.zeros(0, np.float32)]) for c in range(Cn)]
+    want = z["pcm"]
+    peak = max(1.0, float(np.abs(want).max()))
+    for c in range(Cn):
+        assert len(pcm[c]) == want.shape[1] and np.abs(pcm[c] - want[c]).max() <= 4e-6 * peak
