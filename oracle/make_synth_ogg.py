@@ -187,7 +187,11 @@ class Setup:
 def make_setup(rng):
     s = Setup()
     s.channels = int(rng.choice([1, 2, 2, 2, 3, 3, 4, 6]))
+    if os.environ.get("SYNTH_CHANNELS"):  # stress knobs (one-off runs; the committed set uses none)
+        s.channels = int(os.environ["SYNTH_CHANNELS"])
     s.bs0, s.bs1 = [(64, 256), (128, 1024), (256, 2048), (256, 2048), (512, 512), (64, 64), (128, 512), (256, 2048), (512, 4096)][int(rng.integers(0, 9))]
+    if os.environ.get("SYNTH_BLOCKS"):
+        s.bs0, s.bs1 = (int(v) for v in os.environ["SYNTH_BLOCKS"].split("/"))
     s.rate = 44100
     books = []
 
@@ -518,7 +522,7 @@ def make_stream(seed):
     comment = b"\x03vorbis" + struct.pack("<I", len(vendor)) + vendor + struct.pack("<I", 1) + struct.pack("<I", 6) + b"SEED=%d" % (seed % 10) + b"\x01"
     comment = b"\x03vorbis" + struct.pack("<I", len(vendor)) + vendor + struct.pack("<I", 0) + b"\x01"
     setup = write_setup(s)
-    npk = int(rng.integers(8, 20))
+    npk = int(os.environ.get("SYNTH_PACKETS", 0)) or int(rng.integers(8, 20))
     flags = [int(rng.random() < 0.55) for _ in range(npk)]
     pages = [ogg_page(77, 0, 0, [ident], bos=True), ogg_page(77, 1, 0, [comment, setup])]
     seq, pos, prev_n, batch = 2, 0, 0, []

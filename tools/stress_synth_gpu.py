@@ -16,7 +16,7 @@ chans = [int(z["channels"]) for z in gold]
 worst = 0.0
 for vq in ("1", "0"):
     os.environ["PARSEOGGVORBIS_VQ"] = vq
-    frames, sums, ok, pcm, stats = _run_corpus(blobs, chans, threads=4, feeders=2, files_per_submit=7, cap=65536)
+    frames, sums, ok, pcm, stats = _run_corpus(blobs, chans, threads=4, feeders=2, files_per_submit=7, cap=262144)
     for i, z in enumerate(gold):
         want = z["pcm"]
         assert ok[i] and frames[i] == want.shape[1], (names[i], ok[i], frames[i], want.shape)
