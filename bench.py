@@ -174,11 +174,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    # Rehearsal knobs for a ONE-GPU box (never set by the driver): BENCH_FORCE_DEVICE=0 puts every rank on that device and
+    # BENCH_DIST_BACKEND=gloo carries the three tiny collectives (RCCL refuses two ranks on one GPU), so that the N > 1 code path
+    # — setup broadcast, barriers, max-clock / summed-count reduction — can be run for real before a multi-GPU node does it.
+    if os.environ.get("BENCH_FORCE_DEVICE"):
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with WORLD_SIZE == --gpus (one process per GPU)"
 
     if args.workload == "config5":
