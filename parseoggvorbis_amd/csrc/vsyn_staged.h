@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_
 // on the chip, next to the synthesis kernel. Dynamic LDS: layout_lds_bytes().
 #define LAYOUT_THREADS 256
 #define LAYOUT_THREADS_SHORT 64
-#define LAYOUT_SHORT_PACKETS 512u
+#define LAYOUT_SHORT_PACKETS 256u
 static inline __host__ __device__ size_t layout_lds_bytes(uint32_t threads, uint32_t bitmap_packets) {
   return (size_t)threads * (sizeof(AbsScan) + sizeof(uint64_t)) + (size_t)((bitmap_packets + 31u) / 32u) * 4u + 16u;
 }
