@@ -526,7 +526,10 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   hipStream_t ps = overlap_pre ? h->pre : s;
   if (h->main_done_valid[wb]) HIPCHK(hipStreamWaitEvent(ps, h->ev_main_done[wb], 0));
   {
-    const uint32_t lt = max_seg_packets <= LAYOUT_SHORT_PACKETS ? LAYOUT_THREADS_SHORT : LAYOUT_THREADS;
+    // (a 1024-thread block cannot sit next to a synthesis workgroup: it pays only when the serial scan of a very long segment
+    //  would otherwise dominate — 1 x 65536 packets: 105 -> 128 M packets/s, but 16 x 4096: 221 -> 191 M)
+    const uint32_t lt = max_seg_packets <= LAYOUT_SHORT_PACKETS ? LAYOUT_THREADS_SHORT
+                        : (max_seg_packets > LAYOUT_LONG_PACKETS ? LAYOUT_THREADS_LONG : LAYOUT_THREADS);
     const uint32_t bitmap_packets = std::min<uint32_t>(max_seg_packets, LAYOUT_BITMAP_PACKETS);
     vsyn_layout_kernel<<<S, lt, layout_lds_bytes(lt, bitmap_packets), ps>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len,
                                                                           h->d_status, R, force_staged ? 0u : h->fused_mask, list, cnt, cnt_next, segmap,

@@ -74,11 +74,13 @@ __device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_
 // on the chip, next to the synthesis kernel. Dynamic LDS: layout_lds_bytes().
 #define LAYOUT_THREADS 256
 #define LAYOUT_THREADS_SHORT 64
+#define LAYOUT_THREADS_LONG 1024   /* only for batches with a segment beyond LAYOUT_LONG_PACKETS: few, very long streams */
+#define LAYOUT_LONG_PACKETS 16384u
 #define LAYOUT_SHORT_PACKETS 256u
 static inline __host__ __device__ size_t layout_lds_bytes(uint32_t threads, uint32_t bitmap_packets) {
   return (size_t)threads * (sizeof(AbsScan) + sizeof(uint64_t)) + (size_t)((bitmap_packets + 31u) / 32u) * 4u + 16u;
 }
-__global__ void __launch_bounds__(LAYOUT_THREADS)
+__global__ void __launch_bounds__(LAYOUT_THREADS_LONG)
 vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet* __restrict__ pk, uint32_t S,
                    const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
                    SegInfo* __restrict__ sinfo, StreamState* __restrict__ state, uint32_t* __restrict__ emit_len,

@@ -82,7 +82,8 @@ SHAPES = [  # (channels, bs0, bs1, pattern, streams, packets)
     (3, 128, 1024, "mixed", 3, 21),
     (2, 512, 512, "short", 2, 8),
     (2, 2048, 4096, "mixed", 2, 12),
-    (2, 256, 2048, "mixed", 2, 2300),  # segments beyond 2048 packets: the layout kernel's wide block
+    (2, 256, 2048, "mixed", 2, 2300),  # segments of several thousand packets: the layout kernel's bursts
+    (1, 256, 2048, "mixed", 1, 16500),  # one very long segment: the layout kernel's 1024-thread block
 ]
 
 
