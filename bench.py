@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--feature-taps", action="store_true",
+                    help="config3/config4: also write the feature taps of SURVEY 8 f-4 (rendered floor curve u16 + unwrapped posts) — the tap "
+                         "variant of the fused kernel; +4 KB per stereo long packet")
     ap.add_argument("--pcm-s16", action="store_true",
                     help="config3/config4: append the PCM post-stage (planar f32 -> interleaved int16, SURVEY 8 f-3) to every step")
     ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config2", "config3_vq", "config5"],
@@ -226,9 +229,14 @@ def main():
         gpu = Synth(spec, device=local, max_streams=args.streams)
         pcm = torch.zeros((b["S"], spec.channels, b["plane"]), device=device)
         emit = torch.zeros(b["P"], dtype=torch.int32, device=device)
+        tap_tuple = None
+        if args.feature_taps:
+            d_curve = torch.zeros(b["residue"].numel(), dtype=torch.int16, device=device)
+            d_final = torch.zeros(b["ys"].numel(), dtype=torch.int16, device=device)
+            tap_tuple = (None, None, d_final.data_ptr(), d_curve.data_ptr())
         step = lambda: gpu.submit_device(b["P"], b["packets"].data_ptr(), b["S"], b["segments"].data_ptr(), b["ppk"],
                                          b["ys"].data_ptr(), b["residue"].data_ptr(), pcm.data_ptr(), b["plane"],
-                                         emit.data_ptr(), None, flags, stream)
+                                         emit.data_ptr(), tap_tuple, flags, stream)
         vq_entries_per_packet = None
         if args.workload == "config3_vq":
             # same batch, but "after_residue" is rebuilt on the device from classification + entry numbers
@@ -293,6 +301,8 @@ def main():
         in_b = float(np.mean([spec.channels * ((int(n) // 2) * 4 + posts[int(n == spec.blocksize1)] * 2) for n in b["n_of"]]))
         out_b = spec.channels * 4.0 * (b["plane"] - 64) / ppk
         bytes_per_unit = in_b + out_b
+        if args.feature_taps:  # + the u16 curve of every bin
+            bytes_per_unit += float(np.mean([spec.channels * (int(n) // 2) * 2 for n in b["n_of"]]))
         wl = ("config3: %d stereo packets, blocksize 2048, %d streams x %d, floor+coupling+IMDCT+window+overlap-add"
               % (b["P"], b["S"], ppk)) if pattern == "long" else \
              ("config4: %d stereo packets, mixed 2048/256 (%.0f%% long), %d streams x %d" % (b["P"], 100 * lng_frac, b["S"], ppk))

@@ -126,6 +126,8 @@ typedef struct vsyn_taps {            /* optional debug taps = the reference's p
                                          with after_residue these are the feature tensors of returnn_import.py:74-115.
                                          Rows of channels without a decoded floor are left untouched */
 } vsyn_taps;
+/* after_envelope / pcm_after_mdct exist only in the staged (any-shape) kernels: asking for either routes the batch through them.
+ * The two feature taps do not: floor_final comes from the unwrap kernel, floor_curve from the tap variant of the fused kernel. */
 
 typedef struct vsyn_status {
   uint32_t flags;                     /* VSYN_ST_* OR-ed over the batch */

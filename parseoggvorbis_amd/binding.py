@@ -282,7 +282,10 @@ class Synth:
         pcm = np.zeros((S, Cn, plane_stride), np.float32)
         emit = np.zeros(P, np.uint32)
         taps, tp = None, None
-        if want_taps:
+        if want_taps == "features":  # the two feature taps only (they do not force the staged kernels)
+            taps = dict(floor_final=np.zeros(ys.size, np.uint16), floor_curve=np.zeros(residue.size, np.uint16))
+            tp = Taps(None, None, taps["floor_final"].ctypes.data, taps["floor_curve"].ctypes.data)
+        elif want_taps:
             taps = dict(after_envelope=np.zeros(residue.size, np.float32),
                         pcm_after_mdct=np.zeros(residue.size * 2, np.float32),
                         floor_final=np.zeros(ys.size, np.uint16),

@@ -494,7 +494,10 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   hipStream_t s = (hipStream_t)hip_stream;
   const ConstHeader& H = h->H;
   const uint32_t C = H.channels;
-  const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct || taps->floor_curve);
+  // The intermediate-signal taps (after_envelope, pcm_after_mdct) exist only in the staged kernels. The feature taps — the rendered
+  // floor curve and the unwrapped posts — do not force them: the posts come from the unwrap kernel either way and
+  // the curve from the tap variant of the fused kernel.
+  const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct);
   const bool force_staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !h->fused_ok;
   const uint32_t R = force_staged ? std::min<uint32_t>(max_seg_packets, 1024u)
                                   : fused_pick_run_len(h->fused, S, C, max_seg_packets, h->num_cus);
@@ -590,6 +593,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     a.run_cls = h->ws_runcls[wb].p;
     a.runs_per_seg = runs_per_seg;
     a.residue = d_residue;
+    a.curve = taps ? taps->floor_curve : nullptr;
     a.fy = fy;
     a.pcm = d_pcm;
     a.carry = h->d_carry;
@@ -601,7 +605,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     a.coupling_mode = (uint32_t)h->fused.coupling_mode;
     if (staged_may_work) HIPCHK(hipEventRecord(h->ev_join, h->side));
     // one launch covers the long-run and the mixed-block runs (each wave takes the path of its run's class)
-    if (h->profile_which == 1 || h->profile_which == 2) HIPCHK(profile_begin(h, s, fused_kernel_name(H)));
+    if (h->profile_which == 1 || h->profile_which == 2) HIPCHK(profile_begin(h, s, a.curve ? "vsyn_fused_tap_kernel" : fused_kernel_name(H)));
     hipError_t e = fused_launch(H, h->fused, a, max_seg_packets, s);
     if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
     if (h->profile_which == 1 || h->profile_which == 2) HIPCHK(profile_end(h, s));

@@ -62,6 +62,7 @@ struct FusedArgs {
   const vsyn_segment* segs;
   const PktInfo* info;
   const SegInfo* sinfo;
+  uint16_t* curve;         // feature tap "floor1 floor" (vsyn_taps.floor_curve) or nullptr; written by the tap variant of the kernel only
   const uint8_t* run_cls;  // [S][runs_per_seg] from the layout kernel: 1 steady long run, 2 mixed-block run, 0 staged, 0xFF none
   const float* residue;
   const uint16_t* fy;
@@ -220,7 +221,7 @@ __device__ __forceinline__ PktScalars pkt_load(const PktInfo* p) {  // p wave-un
 enum { K_REG = 0, K_LDS = 1, K_CARRY = 2 };
 __device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
 
-template <int ROLE, bool MIXED>
+template <int ROLE, bool MIXED, bool TAPC>
 __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb, float4* __restrict__ seg,
                                           lds_f32* cbuf, lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane0, const uint32_t g,
                                           const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c) {
@@ -428,6 +429,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     auto floor_product = [&](const bool L) {
       const float xf0 = (float)(2u * lane);
       float fl[16];
+      uint32_t ci[16];  // TAPC: the table indices = the rendered curve
 #pragma unroll
       for (int grp = 0; grp < 4; ++grp) {
         if (grp != 0 && !L) continue;  // a short block: bins 2 lane, 2 lane + 1 only (the others of group 0 are computed and unused)
@@ -444,8 +446,19 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         for (int i = 0; i < 4; ++i) {
           const int b = 4 * grp + i;
           // the argument is positive (it exceeds a table index >= 0), so the conversion's truncation is the floor
-          fl[b] = T.invdb[(uint32_t)__builtin_fmaf(xf0 + (float)(128 * (b >> 1) + (b & 1)), sgm[i].x, sgm[i].y)];
+          const uint32_t ix = (uint32_t)__builtin_fmaf(xf0 + (float)(128 * (b >> 1) + (b & 1)), sgm[i].x, sgm[i].y);
+          fl[b] = T.invdb[ix];
+          if (TAPC) ci[b] = ix;
         }
+      }
+      if (TAPC && ((pi.own >> c) & 1u)) {
+        // feature tap "floor1 floor" (hpp:585): the integer curve of this channel's bins, u16, packed like the residue — a lane's
+        // bins 2k, 2k+1 are one 32-bit word, a wave-instruction writes 256 contiguous bytes. Channels without a curve of their
+        // own are left alone, as in the staged kernels.
+        uint32_t* dst = (uint32_t*)(A.curve + pi.res_off + (size_t)c * (L ? ML : 128u)) + lane;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t == 0 || L) dst[64 * t] = ci[2 * t] | (ci[2 * t + 1] << 16);
       }
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -669,7 +682,8 @@ static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a
 // class the layout kernel gave its run (1: all long blocks, steady windows, no carry-in -> fused_run; 2: anything else the
 // fused paths cover -> fused_run<.., MIXED = true>) and takes that path; waves of one workgroup may take different ones (they only ever
 // meet their coupling partner, which shares the run and therefore the class).
-__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_kernel(const FusedArgs A) {
+template <bool TAPC>
+__device__ __forceinline__ void fused_kernel_body(const FusedArgs& A) {
   // one LDS block with a fixed member order: the floor entry tables come first so that their addresses fit the 16 bits
   // fused_run packs them into (the whole block is 72 KB)
   struct Lds {
@@ -727,15 +741,20 @@ __global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vs
   // floor-entry block (the entries are 8 bytes: 64 of them fill the first 512 bytes)
   lds_f32* cbw = (lds_f32*)((float*)s_seg[wave] + 128);
   if (cls == 1u) {
-    if (role == 0) fused_run<0, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
-    else if (role == 1) fused_run<1, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
-    else fused_run<2, false>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    if (role == 0) fused_run<0, false, TAPC>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else if (role == 1) fused_run<1, false, TAPC>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else fused_run<2, false, TAPC>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
   } else {
-    if (role == 0) fused_run<0, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
-    else if (role == 1) fused_run<1, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
-    else fused_run<2, true>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    if (role == 0) fused_run<0, true, TAPC>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else if (role == 1) fused_run<1, true, TAPC>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
+    else fused_run<2, true, TAPC>(A, s_t, s_x[wave], s_x[pw], s_seg[wave], cbw, mf, pf, lane, g, sg, si, qa, qb, C, c);
   }
 }
+
+__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_kernel(const FusedArgs A) { fused_kernel_body<false>(A); }
+// the same kernel with the "floor1 floor" feature tap written on the way: its own launch, so that the 16 extra
+// registers of the tap never weigh on the plain kernel
+__global__ void __launch_bounds__(FUSED_WAVES * 64, FUSED_MIN_WAVES_PER_SIMD) vsyn_fused_tap_kernel(const FusedArgs A) { fused_kernel_body<true>(A); }
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -889,7 +908,8 @@ static inline hipError_t fused_launch(const ConstHeader& H, const FusedTables& f
   const char* xl = getenv("VSYN_EXTRA_LDS");  // experiment knob: extra dynamic LDS lowers the occupancy
   const size_t dyn = xl ? (size_t)atoi(xl) : 0;
   a.coupling_mode = (uint32_t)ft.coupling_mode;
-  vsyn_fused_kernel<<<grid, FUSED_WAVES * 64, dyn, s>>>(a);
+  if (a.curve) vsyn_fused_tap_kernel<<<grid, FUSED_WAVES * 64, dyn, s>>>(a);
+  else vsyn_fused_kernel<<<grid, FUSED_WAVES * 64, dyn, s>>>(a);
   return hipGetLastError();
 }
 

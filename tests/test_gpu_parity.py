@@ -328,3 +328,24 @@ def test_garbage_descriptors_and_posts(flags):
               orc.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"]))
         gpu.reset()
         orc = ob.OracleSynth(spec, 3)
+
+
+@pytest.mark.parametrize("pattern,C", [("long", 2), ("mixed", 2), ("mixed", 1)])
+def test_feature_taps_from_the_fused_kernel(pattern, C):
+    """the feature taps alone ("floor1 floor" curve + unwrapped posts) do not leave the fast path — the tap variant
+    of the fused kernel writes the curve on the way. Curve and posts equal the oracle's (integers: exact), PCM as without taps,
+    and the staged kernels produce the very same tap."""
+    spec = fixture_like_spec(C)
+    b = synth_batch(spec, 4, 45, pattern, seed=31, unused_frac=0.15, granule_last=True)
+    want = ob.OracleSynth(spec, 4).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
+    gpu = binding.Synth(spec, max_streams=4)
+    got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps="features")
+    check(got, want)
+    assert np.array_equal(got["taps"]["floor_curve"], want["taps"]["floor_curve"])
+    assert np.array_equal(got["taps"]["floor_final"], want["taps"]["floor_final"])
+    gpu.reset()
+    staged = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
+    assert np.array_equal(staged["taps"]["floor_curve"], got["taps"]["floor_curve"])
+    gpu.reset()
+    plain = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert np.array_equal(bits(plain["pcm"]), bits(got["pcm"]))  # the tap changes nothing else
