@@ -142,6 +142,9 @@ typedef struct vsyn_handle vsyn_handle;
                                          pending on hip_stream). Lets the layout + floor-unwrap kernels of this submit overlap the
                                          synthesis kernel of the previous one; results are identical either way. */
 
+#define VSYN_SUBMIT_KEEP_PCM 4u        /* vsyn_submit_host*: leave the PCM on the device (`pcm` may be NULL, nothing is copied back);
+                                         fetch it in the form the consumer wants with vsyn_pcm_fetch_host */
+
 const char* vsyn_version(void);
 int vsyn_abi_version(void);
 
@@ -275,6 +278,12 @@ int vsyn_pcm_interleave_device(vsyn_handle* h, int format, const float* d_pcm, u
  * can tell that replicas agree — the reference's harness compares decoders sample by sample, compare-debug-out.py:524-542 —
  * without another pass over the PCM on the host. `out` holds S * channels doubles of the last submit. Synchronous. */
 int vsyn_pcm_abs_sum_host(vsyn_handle* h, double* out, const char** err);
+
+/* The PCM of the MOST RECENT vsyn_submit_host* call on this handle, converted on the device and copied to the host in the
+ * interleaved form of vsyn_pcm_interleave_device (VSYN_PCM_S16 / VSYN_PCM_F32): out[g][frame][channel], out_stride_frames
+ * frames per segment; frames_out[g] (optional) = emitted frames of segment g. With VSYN_SUBMIT_KEEP_PCM on the submit, int16
+ * output halves the bytes that cross the bus. Synchronous. */
+int vsyn_pcm_fetch_host(vsyn_handle* h, int format, void* out, uint64_t out_stride_frames, uint32_t* frames_out, const char** err);
 
 /* Page-locked host memory for the buffers handed to vsyn_submit_host (direct DMA instead of the runtime's staging copies;
  * what a host decoder that batches at corpus scale wants). Pageable memory is accepted by vsyn_submit_host as well. */

@@ -19,6 +19,7 @@ VSYN_ST_BAD_SEGMENT, VSYN_ST_BAD_VQ = 32, 64
 VSYN_SEG_RESET = 1
 VSYN_SUBMIT_STAGED = 1
 VSYN_SUBMIT_INPUTS_READY = 2
+VSYN_SUBMIT_KEEP_PCM = 4
 VSYN_PCM_S16, VSYN_PCM_F32 = 1, 2
 
 
@@ -173,7 +174,7 @@ _SYMBOLS = [
     "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels",
     "vsyn_const_block_bytes", "vsyn_submit_device", "vsyn_submit_host", "vsyn_sync_status", "vsyn_reset_streams",
     "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device", "vsyn_host_alloc", "vsyn_host_free",
-    "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq", "vsyn_pcm_interleave_device", "vsyn_pcm_abs_sum_host",
+    "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq", "vsyn_pcm_interleave_device", "vsyn_pcm_abs_sum_host", "vsyn_pcm_fetch_host",
 ]
 
 
@@ -226,6 +227,7 @@ def load():
                                         C.POINTER(Taps), u32, C.POINTER(Status), cpp]
     lib.vsyn_pcm_interleave_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, vp, vp, cpp]
     lib.vsyn_pcm_abs_sum_host.argtypes = [vp, C.POINTER(C.c_double), cpp]
+    lib.vsyn_pcm_fetch_host.argtypes = [vp, C.c_int, vp, u64, vp, cpp]
     lib.vsyn_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp), cpp]
     lib.vsyn_host_free.argtypes = [vp]
     lib.vsyn_host_free.restype = None
@@ -359,6 +361,16 @@ class Synth:
                                                  C.byref(err))
         if rc != VSYN_OK:
             raise VsynError(rc, (err.value or b"").decode())
+
+    def pcm_fetch_host(self, fmt, num_segments, out_stride_frames):
+        """The PCM of the most recent submit_host*, converted on the device -> ([S][out_stride_frames][C] int16 / float32, frames [S])."""
+        out = np.zeros((num_segments, out_stride_frames, self.channels), np.int16 if fmt == VSYN_PCM_S16 else np.float32)
+        frames = np.zeros(num_segments, np.uint32)
+        err = C.c_char_p()
+        rc = self.lib.vsyn_pcm_fetch_host(self.h, fmt, out.ctypes.data, out_stride_frames, frames.ctypes.data, C.byref(err))
+        if rc != VSYN_OK:
+            raise VsynError(rc, (err.value or b"").decode())
+        return out, frames
 
     def pcm_abs_sum_host(self, num_segments):
         """Per-(segment, channel) sum |x| of the PCM of the most recent submit_host*, computed on the device -> [S][C] float64."""

@@ -129,6 +129,8 @@ struct vsyn_handle {
   DevBuf<uint16_t> st_curve;
   DevBuf<uint32_t> st_emit;
   DevBuf<double> st_sum;               // vsyn_pcm_abs_sum_host
+  DevBuf<uint8_t> st_conv;             // vsyn_pcm_fetch_host: interleaved output
+  DevBuf<uint32_t> st_frames;
   uint64_t last_host_plane = 0;        // plane_stride of the most recent vsyn_submit_host* (0: none yet)
   // profiling
   bool profile = false;
@@ -672,7 +674,8 @@ static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packe
     status->first_bad_packet = 0xFFFFFFFFu;
   }
   if (P == 0 || S == 0) return VSYN_OK;
-  if (!packets || !segments || !ys || (!residue && !vq) || !pcm) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
+  const bool keep_pcm = (flags & VSYN_SUBMIT_KEEP_PCM) != 0;
+  if (!packets || !segments || !ys || (!residue && !vq) || (!pcm && !keep_pcm)) return fail(err, VSYN_ERR_INVALID, "NULL batch pointer");
   if (vq) {
     if (!h->d_vq) return fail(err, VSYN_ERR_INVALID, "vsyn_attach_vq has not been called on this handle");
     if (!vq->packets || (vq->num_cls && !vq->cls) || (vq->num_entries && !vq->entries)) return fail(err, VSYN_ERR_INVALID, "NULL vq batch pointer");
@@ -751,12 +754,12 @@ static int submit_host_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* packe
   if (dt.pcm_after_mdct) HIPCHK(hipMemsetAsync(dt.pcm_after_mdct, 0, sizeof(float) * 2 * residue_floats, hs));
   const bool any_tap = dt.after_envelope || dt.pcm_after_mdct || dt.floor_final || dt.floor_curve;
   int rc = submit_device_impl(h, P, h->st_pk.p, S, h->st_seg.p, max_seg, h->st_ys.p, vq ? &dvq : nullptr, h->st_res.p, h->st_pcm.p, plane_stride,
-                              h->st_emit.p, any_tap ? &dt : nullptr, flags & ~VSYN_SUBMIT_INPUTS_READY, hs, err);
+                              h->st_emit.p, any_tap ? &dt : nullptr, flags & ~(VSYN_SUBMIT_INPUTS_READY | VSYN_SUBMIT_KEEP_PCM), hs, err);
   if (rc) return rc;
   h->last_host_plane = plane_stride;
   if (vq && residue_out) HIPCHK(hipMemcpyAsync(residue_out, h->st_res.p, sizeof(float) * residue_floats, hipMemcpyDeviceToHost, hs));
   // results are queued behind the kernels before the one host wait
-  HIPCHK(hipMemcpyAsync(pcm, h->st_pcm.p, sizeof(float) * pcm_n, hipMemcpyDeviceToHost, hs));
+  if (!keep_pcm) HIPCHK(hipMemcpyAsync(pcm, h->st_pcm.p, sizeof(float) * pcm_n, hipMemcpyDeviceToHost, hs));
   if (emit_len) HIPCHK(hipMemcpyAsync(emit_len, h->st_emit.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, hs));
   if (dt.after_envelope) HIPCHK(hipMemcpyAsync(taps->after_envelope, dt.after_envelope, sizeof(float) * residue_floats, hipMemcpyDeviceToHost, hs));
   if (dt.pcm_after_mdct) HIPCHK(hipMemcpyAsync(taps->pcm_after_mdct, dt.pcm_after_mdct, sizeof(float) * 2 * residue_floats, hipMemcpyDeviceToHost, hs));
@@ -802,6 +805,34 @@ int vsyn_pcm_interleave_device(vsyn_handle* h, int format, const float* d_pcm, u
   else
     vsyn_pcm_interleave_kernel<VSYN_PCM_F32><<<grid, 256, 0, s>>>(h->d_const, si, h->last_S, d_pcm, plane_stride, d_out, out_stride_frames, d_frames);
   HIPCHK(hipGetLastError());
+  return VSYN_OK;
+}
+
+int vsyn_pcm_fetch_host(vsyn_handle* h, int format, void* out, uint64_t out_stride_frames, uint32_t* frames_out, const char** err) {
+  if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
+  if (format != VSYN_PCM_S16 && format != VSYN_PCM_F32) return fail(err, VSYN_ERR_INVALID, "unknown PCM format %d", format);
+  if (!out || out_stride_frames == 0) return fail(err, VSYN_ERR_INVALID, "NULL pointer / zero stride");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->last_S == 0 || h->last_host_plane == 0) return fail(err, VSYN_ERR_INVALID, "no vsyn_submit_host on this handle yet");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t elem = format == VSYN_PCM_S16 ? 2 : 4;
+  const size_t bytes = (size_t)h->last_S * out_stride_frames * h->H.channels * elem;
+  HIPCHK(h->st_conv.ensure(bytes + 16));
+  HIPCHK(h->st_frames.ensure(h->last_S));
+  hipStream_t s = h->host_stream;
+  const uint64_t cap = std::min<uint64_t>(std::min<uint64_t>(h->last_host_plane, out_stride_frames), 0xFFFFFFFFull);
+  const dim3 grid((uint32_t)((cap + 1023) / 1024), h->last_S);
+  const SegInfo* si = h->ws_seg[h->last_wb].p;
+  if (format == VSYN_PCM_S16)
+    vsyn_pcm_interleave_kernel<VSYN_PCM_S16><<<grid, 256, 0, s>>>(h->d_const, si, h->last_S, h->st_pcm.p, h->last_host_plane, h->st_conv.p, out_stride_frames,
+                                                                 h->st_frames.p);
+  else
+    vsyn_pcm_interleave_kernel<VSYN_PCM_F32><<<grid, 256, 0, s>>>(h->d_const, si, h->last_S, h->st_pcm.p, h->last_host_plane, h->st_conv.p, out_stride_frames,
+                                                                 h->st_frames.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, h->st_conv.p, bytes, hipMemcpyDeviceToHost, s));
+  if (frames_out) HIPCHK(hipMemcpyAsync(frames_out, h->st_frames.p, sizeof(uint32_t) * h->last_S, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   return VSYN_OK;
 }
 

@@ -179,6 +179,7 @@ struct Group {
   PinnedArray<vsyn_segment> seg;
   PinnedArray<uint16_t> ys;
   PinnedArray<float> residue, pcm;
+  PinnedArray<int16_t> pcm16;  // CorpusOptions::pcm_s16: [S][plane][C]
   PinnedArray<uint32_t> emit;
   bool vq = false;  // files of this group ship classification + entry numbers instead of residue floats
   PinnedArray<vsyn_vq_packet> vq_pk;
@@ -248,7 +249,8 @@ struct Feeder {
       CHECK_ERR(g.residue.ensure(rfloats));
     }
     CHECK_ERR(g.emit.ensure(P));
-    CHECK_ERR(g.pcm.ensure((size_t)S * C * plane));
+    if (opts.pcm_s16) CHECK_ERR(g.pcm16.ensure((size_t)S * C * plane));
+    else CHECK_ERR(g.pcm.ensure((size_t)S * C * plane));
     size_t p0 = 0, r0 = 0, c0 = 0, e0 = 0;
     for (uint32_t s = 0; s < S; ++s) {
       const PacketBatch& b = g.pending[s]->batch;
@@ -285,6 +287,7 @@ struct Feeder {
     vsyn_status st = {0, 0xffffffffu};
     const char* err = nullptr;
     int rc;
+    const uint32_t sflags = opts.pcm_s16 ? VSYN_SUBMIT_KEEP_PCM : 0u;
     if (g.vq) {
       vsyn_vq_batch vqb;
       vqb.packets = g.vq_pk.p;
@@ -292,9 +295,14 @@ struct Feeder {
       vqb.entries = g.entries.p;
       vqb.num_cls = ncls;
       vqb.num_entries = nent;
-      rc = vsyn_submit_host_vq(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, &vqb, nullptr, rfloats, g.pcm.p, plane, g.emit.p, nullptr, 0, &st, &err);
+      rc = vsyn_submit_host_vq(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, &vqb, nullptr, rfloats, opts.pcm_s16 ? nullptr : g.pcm.p, plane, g.emit.p, nullptr, sflags, &st, &err);
     } else {
-      rc = vsyn_submit_host(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, g.residue.p, rfloats, g.pcm.p, plane, g.emit.p, nullptr, 0, &st, &err);
+      rc = vsyn_submit_host(g.handle, (uint32_t)P, g.pk.p, S, g.seg.p, g.ys.p, g.residue.p, rfloats, opts.pcm_s16 ? nullptr : g.pcm.p, plane, g.emit.p, nullptr, sflags, &st, &err);
+    }
+    if (opts.pcm_s16 && rc == VSYN_OK) {
+      const char* ferr = nullptr;
+      if (vsyn_pcm_fetch_host(g.handle, VSYN_PCM_S16, g.pcm16.p, plane, nullptr, &ferr) != VSYN_OK)
+        return OkOrError(std::string("GPU synthesis layer: ") + (ferr ? ferr : "pcm fetch failed"));
     }
     // per-(file, channel) digests from the device, where the PCM still is (a host pass over it cost more than the decode's GPU calls)
     std::vector<double> digest;
@@ -337,9 +345,12 @@ struct Feeder {
         CHECK(frames <= plane);
         double acc = 0;
         for (uint32_t c = 0; c < C; ++c) {
-          const float* x = &g.pcm[((size_t)s * C + c) * plane];
-          chans[c] = DataRange<const float>(x, frames);
-          if (opts.checksum) acc += digest.empty() ? abs_sum_f32(x, frames) : digest[(size_t)s * C + c];
+          if (!opts.pcm_s16) {
+            const float* x = &g.pcm[((size_t)s * C + c) * plane];
+            chans[c] = DataRange<const float>(x, frames);
+            if (opts.checksum && digest.empty()) acc += abs_sum_f32(x, frames);
+          }
+          if (opts.checksum && !digest.empty()) acc += digest[(size_t)s * C + c];
         }
         out.frames = frames;
         out.abs_sum = acc;
@@ -347,7 +358,11 @@ struct Feeder {
         stats.frames += frames;
         if (callbacks) {
           std::lock_guard<std::mutex> lk(callbacks_mu);
-          if (!callbacks->gotFilePcm(r.index, r.header, chans)) return OkOrError("aborted by gotFilePcm");
+          if (opts.pcm_s16) {
+            if (!callbacks->gotFilePcmS16(r.index, r.header, &g.pcm16[(size_t)s * plane * C], frames)) return OkOrError("aborted by gotFilePcmS16");
+          } else if (!callbacks->gotFilePcm(r.index, r.header, chans)) {
+            return OkOrError("aborted by gotFilePcm");
+          }
         }
       }
       stats.audio_packets += r.batch.pk.size();
@@ -554,5 +569,55 @@ extern "C" int ogg_vorbis_decode_corpus(const uint8_t* const* datas, const size_
     return 1;
   }
   if (error_out) *error_out = nullptr;
+  return 0;
+}
+
+// The same with int16 output (CorpusOptions::pcm_s16): pcm16_out[i] (may be NULL) receives the file's interleaved frames,
+// at most pcm_capacity_frames[i] of them (a longer file is marked failed).
+extern "C" int ogg_vorbis_decode_corpus_s16(const uint8_t* const* datas, const size_t* lens, size_t num_files, int threads, int feeders,
+                                            uint32_t files_per_submit, int device, uint64_t* frames_out, uint8_t* ok_out, int16_t* const* pcm16_out,
+                                            const uint64_t* pcm_capacity_frames, double* stats_out, const char** error_out) {
+  static char error_buf[256];
+  std::vector<CorpusItem> items(num_files);
+  for (size_t i = 0; i < num_files; ++i) items[i] = CorpusItem{datas[i], lens[i]};
+  CorpusOptions opts;
+  opts.threads = threads;
+  opts.feeders = feeders;
+  opts.files_per_submit = files_per_submit;
+  opts.device = device;
+  opts.pcm_s16 = true;
+  std::vector<CorpusFileResult> results;
+  CorpusStats st;
+  struct CopyOut : CorpusCallbacks {
+    int16_t* const* out;
+    const uint64_t* cap;
+    std::vector<uint8_t> too_long;
+    bool gotFilePcmS16(size_t i, const VorbisIdHeader& h, const int16_t* x, uint64_t frames) override {
+      if (!out || !out[i]) return true;
+      if (frames > cap[i]) {
+        too_long[i] = 1;
+        return true;
+      }
+      memcpy(out[i], x, (size_t)frames * h.audio_channels * sizeof(int16_t));
+      return true;
+    }
+  } copy_out;
+  copy_out.out = pcm16_out;
+  copy_out.cap = pcm_capacity_frames;
+  copy_out.too_long.assign(num_files, 0);
+  OkOrError r = decode_corpus(items, opts, pcm16_out && pcm_capacity_frames ? &copy_out : nullptr, results, &st);
+  for (size_t i = 0; i < results.size() && i < num_files; ++i) {
+    if (frames_out) frames_out[i] = results[i].frames;
+    if (ok_out) ok_out[i] = results[i].status.is_error_ || copy_out.too_long[i] ? 0 : 1;
+  }
+  if (stats_out) {
+    const double v[8] = {st.wall_s, st.entropy_cpu_s, st.gpu_call_s, st.pack_s, st.deliver_s, (double)st.submits, (double)st.audio_packets, (double)st.frames};
+    for (int i = 0; i < 8; ++i) stats_out[i] = v[i];
+  }
+  if (r.is_error_) {
+    snprintf(error_buf, sizeof(error_buf), "%s", r.err_msg_.c_str());
+    if (error_out) *error_out = error_buf;
+    return 1;
+  }
   return 0;
 }

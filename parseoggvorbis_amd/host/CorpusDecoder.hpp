@@ -46,6 +46,12 @@ struct CorpusCallbacks {
     (void)file_index; (void)header; (void)channelPcms;
     return true;
   }
+  // CorpusOptions::pcm_s16: the file's PCM as interleaved host-endian int16 frames (ov_read's conversion, done on the device: half
+  // the bytes cross the bus), valid during the call
+  virtual bool gotFilePcmS16(size_t file_index, const VorbisIdHeader& header, const int16_t* interleaved, uint64_t frames) {
+    (void)file_index; (void)header; (void)interleaved; (void)frames;
+    return true;
+  }
 };
 
 struct CorpusOptions {
@@ -57,6 +63,7 @@ struct CorpusOptions {
   bool entropy_only = false;        // diagnostic: run the workers only and count packets (no GPU call, no PCM, frames stay 0)
   bool share_setups = true;         // parse byte-identical setup headers once per run (SetupCache)
   bool checksum = true;             // fill CorpusFileResult::abs_sum (digest computed on the device, vsyn_pcm_abs_sum_host)
+  bool pcm_s16 = false;             // deliver interleaved int16 (gotFilePcmS16) instead of planar f32 (SURVEY 8 f-3 on the host path)
 };
 
 struct CorpusStats {
@@ -85,6 +92,10 @@ extern "C" {
 int ogg_vorbis_decode_corpus(const uint8_t* const* datas, const size_t* lens, size_t num_files, int threads, int feeders,
                              uint32_t files_per_submit, int device, uint64_t* frames_out, double* abs_sum_out, uint8_t* ok_out, float* const* pcm_out,
                              const uint64_t* pcm_capacity, double* stats_out, const char** error_out);
+// int16 output (CorpusOptions::pcm_s16): pcm16_out[i] = NULL or room for pcm_capacity_frames[i] interleaved frames
+int ogg_vorbis_decode_corpus_s16(const uint8_t* const* datas, const size_t* lens, size_t num_files, int threads, int feeders,
+                                 uint32_t files_per_submit, int device, uint64_t* frames_out, uint8_t* ok_out, int16_t* const* pcm16_out,
+                                 const uint64_t* pcm_capacity_frames, double* stats_out, const char** error_out);
 }
 
 #endif

@@ -1,5 +1,5 @@
 // corpus_main.cpp — decode a corpus of Ogg Vorbis files with T entropy threads and one GPU, print one JSON line.
-//   corpus_hip.bin [--threads T] [--feeders F] [--files_per_submit K] [--replicas N] [--device D] [--entropy_only] [--no_setup_cache] [--no_checksum] file.ogg [file.ogg ...]
+//   corpus_hip.bin [--threads T] [--feeders F] [--files_per_submit K] [--replicas N] [--device D] [--entropy_only] [--no_setup_cache] [--no_checksum] [--s16] file.ogg [file.ogg ...]
 // --replicas N decodes every listed file N times (N independent decodes from the same bytes in memory): the way to get a
 // corpus-sized run out of the two fixture files when there is no corpus on the box.
 #include <stdio.h>
@@ -44,6 +44,7 @@ int main(int argc, const char** argv) {
     else if (a == "--entropy_only") opts.entropy_only = true;
     else if (a == "--no_setup_cache") opts.share_setups = false;
     else if (a == "--no_checksum") opts.checksum = false;
+    else if (a == "--s16") opts.pcm_s16 = true;
     else if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
       fprintf(stderr, "unknown option %s\n", a.c_str());
       return 2;

@@ -277,3 +277,34 @@ def test_cli_dump_matches_reference_on_synthetic_streams(name, tmp_path):
     peak = max(1.0, float(np.abs(want).max()))
     for c in range(Cn):
         assert len(pcm[c]) == want.shape[1] and np.abs(pcm[c] - want[c]).max() <= 4e-6 * peak
+
+
+def test_corpus_decoder_int16_output():
+    """CorpusOptions::pcm_s16 (SURVEY 8 f-3 on the host path): the PCM leaves the device as interleaved int16 — ov_read's
+    conversion applied on the GPU, half the bytes over the bus. Equal to the oracle's conversion of the float PCM the same
+    decoder delivers otherwise, for real and synthetic files (1-6 channels)."""
+    from oracle import oracle_binding as ob
+    names = ["test.stereo44khz", "test.mono44khz"] + _synth_names()[:6]
+    blobs = [open(os.path.join(GOLDEN, n + ".ogg"), "rb").read() for n in names]
+    chans = [int(np.load(os.path.join(GOLDEN, n + ".npz"))["channels"]) for n in names]
+    frames, sums, ok, pcm, stats = _run_corpus(blobs, chans, threads=3, feeders=2, files_per_submit=3, cap=131072)
+    assert all(ok)
+    lib = _corpus_lib()
+    lib.ogg_vorbis_decode_corpus_s16.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_char_p)]
+    lib.ogg_vorbis_decode_corpus_s16.restype = C.c_int
+    n = len(blobs)
+    datas = (C.c_char_p * n)(*blobs)
+    lens = (C.c_size_t * n)(*[len(b) for b in blobs])
+    fr = (C.c_uint64 * n)()
+    ok16 = (C.c_uint8 * n)()
+    out = [np.zeros((131072, chans[i]), np.int16) for i in range(n)]
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in out])
+    caps = (C.c_uint64 * n)(*([131072] * n))
+    err = C.c_char_p()
+    assert lib.ogg_vorbis_decode_corpus_s16(datas, lens, n, 3, 2, 3, 0, fr, ok16, ptrs, caps, None, C.byref(err)) == 0, err.value
+    for i in range(n):
+        assert ok16[i] and fr[i] == frames[i], names[i]
+        want = ob.pcm_interleave(1, np.ascontiguousarray(pcm[i][:, :frames[i]]), frames[i])
+        assert np.array_equal(out[i][:frames[i]], want), names[i]

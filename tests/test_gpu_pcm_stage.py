@@ -81,3 +81,32 @@ def test_pcm_abs_sum_host_matches_numpy():
         assert np.allclose(d1[s], want, rtol=1e-12, atol=0)
     r2 = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
     assert r2["rc"] == 0 and np.array_equal(gpu.pcm_abs_sum_host(5).view(np.uint64), d1.view(np.uint64))
+
+
+def test_pcm_fetch_host_converted_on_the_device():
+    """Host path of the post-stage: VSYN_SUBMIT_KEEP_PCM leaves the planar f32 PCM on the device (nothing comes back with the
+    submit), vsyn_pcm_fetch_host brings it back interleaved as int16 (half the bytes; ov_read's conversion, exact against the
+    oracle's restatement) or as f32 (the planar values, interleaved)."""
+    import numpy as np
+    from parseoggvorbis_amd import binding
+    from parseoggvorbis_amd.binding import VSYN_SUBMIT_KEEP_PCM
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, 3, 21, "mixed", seed=12, granule_last=True)
+    gpu = binding.Synth(spec, max_streams=3)
+    ref = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert ref["rc"] == 0
+    gpu.reset()
+    kept = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=VSYN_SUBMIT_KEEP_PCM)
+    assert kept["rc"] == 0 and not kept["pcm"].any() and np.array_equal(kept["emit_len"], ref["emit_len"])
+    per = len(b["packets"]) // 3
+    stride = b["plane_stride"]
+    s16, frames = gpu.pcm_fetch_host(VSYN_PCM_S16, 3, stride)
+    f32, frames2 = gpu.pcm_fetch_host(VSYN_PCM_F32, 3, stride)
+    assert np.array_equal(frames, frames2)
+    for s in range(3):
+        n = int(ref["emit_len"][s * per:(s + 1) * per].sum())
+        assert int(frames[s]) == n
+        assert np.array_equal(f32[s, :n], ref["pcm"][s][:, :n].T)
+        want = ob.pcm_interleave(VSYN_PCM_S16, np.ascontiguousarray(ref["pcm"][s][:, :n]), n)
+        assert np.array_equal(s16[s, :n], want)
+        assert not s16[s, n:].any()
