@@ -281,7 +281,7 @@ int vsyn_pcm_abs_sum_host(vsyn_handle* h, double* out, const char** err);
 
 /* The PCM of the MOST RECENT vsyn_submit_host* call on this handle, converted on the device and copied to the host in the
  * interleaved form of vsyn_pcm_interleave_device (VSYN_PCM_S16 / VSYN_PCM_F32): out[g][frame][channel], out_stride_frames
- * frames per segment; frames_out[g] (optional) = emitted frames of segment g. With VSYN_SUBMIT_KEEP_PCM on the submit, int16
+ * frames per segment (frames past a segment's end are zero); frames_out[g] (optional) = emitted frames of segment g. With VSYN_SUBMIT_KEEP_PCM on the submit, int16
  * output halves the bytes that cross the bus. Synchronous. */
 int vsyn_pcm_fetch_host(vsyn_handle* h, int format, void* out, uint64_t out_stride_frames, uint32_t* frames_out, const char** err);
 

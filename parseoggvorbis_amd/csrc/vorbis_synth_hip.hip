@@ -820,6 +820,7 @@ int vsyn_pcm_fetch_host(vsyn_handle* h, int format, void* out, uint64_t out_stri
   HIPCHK(h->st_conv.ensure(bytes + 16));
   HIPCHK(h->st_frames.ensure(h->last_S));
   hipStream_t s = h->host_stream;
+  HIPCHK(hipMemsetAsync(h->st_conv.p, 0, bytes, s));  // frames past a segment's end come back as silence, not as stale staging memory
   const uint64_t cap = std::min<uint64_t>(std::min<uint64_t>(h->last_host_plane, out_stride_frames), 0xFFFFFFFFull);
   const dim3 grid((uint32_t)((cap + 1023) / 1024), h->last_S);
   const SegInfo* si = h->ws_seg[h->last_wb].p;
