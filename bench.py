@@ -434,7 +434,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the committed summary of
     # the separate rocprofv3 --pmc passes over this same command (tools/profile_round.sh -> profiles/) is reported when it
     # describes this kernel and workload
-    traffic = None
+    traffic, traffic_detail = None, None
     if rank == 0 and args.workload == "config3" and not args.staged:
         try:
             import glob
@@ -442,13 +442,16 @@ def main():
             pm = json.load(open(latest))
             hb = pm.get("long_kernel_hbm_bytes_per_launch")
             if hb and kern_name in pm.get("kernels", {}):
-                traffic = {"bytes_per_launch": round(hb["read_corrected"] + hb["write"]), "read_corrected": round(hb["read_corrected"]),
-                           "write": round(hb["write"]), "source": "profiles/" + os.path.basename(latest)}
+                traffic = round(hb["read_corrected"] + hb["write"])  # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)
+                traffic_detail = {"read_corrected": round(hb["read_corrected"]), "write": round(hb["write"]),
+                                  "algorithmic_bytes_per_launch": None, "source": "profiles/" + os.path.basename(latest)}
         except Exception:
-            traffic = None
+            traffic, traffic_detail = None, None
     if rank == 0:
         value = total_units * args.steps / dt
         achieved = bytes_per_unit * units / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+        if traffic_detail is not None:
+            traffic_detail["algorithmic_bytes_per_launch"] = round(bytes_per_unit * units)
         line = {
             "metric": "audio packets/sec (blocksize 2048, stereo)" if args.workload == "config3" else "audio packets/sec",
             "value": round(value, 1), "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -457,6 +460,7 @@ def main():
             "config": {"workload": wl, "packets_per_gpu": units, "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_detail": traffic_detail,
                          "kernel": kern_name, "kernel_ms": round(kern_ms, 5), "launches": launches,
                          "algorithmic_bytes_per_packet": round(bytes_per_unit, 1)},
             "cpu_baseline": cpu, "pcm_stage_s16": pcm_stage,
