@@ -20,11 +20,12 @@
 //               the same sequence of f32 additions as the reference —, then stores each element once (format 2 de-interleaved,
 //               16-byte stores).  No atomics.  Only passes in which the residue has a codebook at all are visited (a scalar loop
 //               over the set bits); vector lengths 1, 2, 4 and 8+ (powers of two) read their entries from LDS and their value
-//               vectors with whole-vector loads; an out-of-range entry number reads the zero vector that heads the pool (and
-//               raises the status); format 0, odd lengths and partition tails go through one out-of-line per-element routine.
+//               vectors with whole-vector loads through a buffer descriptor over the pool (32-bit offsets, hardware bounds check: an
+//               out-of-range entry number raises the status and can only read other table data or zeros, never outside the pool); format 0, odd lengths and partition tails go through one out-of-line per-element routine.
 //   zero fill   the bins outside the partitions are two runs of consecutive bins per channel.
 // A single wave needs no barriers: its LDS operations execute in order.
-// Measured (bench.py --workload config3_vq, 65 536 stereo long packets, kernel time): this design 0.29 ms — VALU issue is
+// Measured (bench.py --workload config3_vq, 65 536 stereo long packets, kernel time): this design 0.285 ms (0.294 with plain
+// global loads + a select per entry) — VALU issue is
 // what binds it now (1376 VALU wave-instructions per packet at 45 % lane utilisation: the lanes of a wave hold different
 // classes, so every vector-length variant of a pass runs).  Its predecessor (entries and classifications read from global
 // memory inside the accumulate loop, per-pass LDS book records, zero fill element by element) 0.48 ms; earlier alternatives:
@@ -143,7 +144,7 @@ template <bool ENT_LDS>
 __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t lane, const bool bad, const VqCp* s_cp,
                                                const uint16_t* s_pp, const vq_u32x4* s_start, const uint16_t* s_ent, const uint8_t* s_vm,
                                                const uint8_t* s_cls, const uint8_t* s_chan, const uint16_t* __restrict__ eg,
-                                               const float* __restrict__ pool, float* __restrict__ out) {
+                                               const __amdgpu_buffer_rsrc_t pool, float* __restrict__ out) {
   auto entry = [&](uint32_t i) -> uint32_t { return ENT_LDS ? (uint32_t)s_ent[X.ent_shift + i] : (uint32_t)eg[i]; };
   const uint32_t groups = X.npj * X.gpp;
   const bool full8 = (X.psize & (VQ_GROUP - 1u)) == 0u;
@@ -176,22 +177,25 @@ __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t 
         const uint32_t nent1 = cp.inf & 0xFFFFu, sh = (cp.inf >> 16) & 15u;
         float add[VQ_GROUP];
         if ((cp.inf & VQ_CP_FAST) && cnt_el == VQ_GROUP) {
-          // out-of-range entry numbers read the zero vector at the start of the pool instead
+          // The value tables are read through a buffer descriptor over the pool: 32-bit offsets (no 64-bit address arithmetic) and
+          // hardware bounds checking — an out-of-range entry number can only read other table data or, past the pool, zeros; it is
+          // flagged (the packet's values are unspecified then), never dereferenced outside the pool.
+          typedef float vq_f4 __attribute__((ext_vector_type(4)));
+          typedef float vq_f2 __attribute__((ext_vector_type(2)));
           if (sh >= 3u) {         // one vector covers the group's 8 elements: 8 consecutive components
             const uint32_t en = entry(e0 + (w0 >> sh));
-            const bool ok = en <= nent1;
-            bad_entry |= !ok;
-            const float4* v4 = (const float4*)(pool + (ok ? cp.tab + (en << sh) + (w0 & ((1u << sh) - 1u)) : 0u));
-            const float4 a = v4[0], b = v4[1];
+            bad_entry |= en > nent1;
+            const uint32_t off = (cp.tab + (en << sh) + (w0 & ((1u << sh) - 1u))) * 4u;
+            const vq_f4 a = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, off, 0, 0));
+            const vq_f4 b = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, off + 16u, 0, 0));
             add[0] = a.x; add[1] = a.y; add[2] = a.z; add[3] = a.w;
             add[4] = b.x; add[5] = b.y; add[6] = b.z; add[7] = b.w;
           } else if (sh == 2u) {  // two vectors of 4
             const uint32_t i0 = e0 + (w0 >> 2);
             const uint32_t en0 = entry(i0), en1 = entry(i0 + 1u);
-            const bool ok0 = en0 <= nent1, ok1 = en1 <= nent1;
-            bad_entry |= !(ok0 && ok1);
-            const float4 a = *(const float4*)(pool + (ok0 ? cp.tab + en0 * 4u : 0u));
-            const float4 b = *(const float4*)(pool + (ok1 ? cp.tab + en1 * 4u : 0u));
+            bad_entry |= (en0 > nent1) | (en1 > nent1);
+            const vq_f4 a = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, (cp.tab + en0 * 4u) * 4u, 0, 0));
+            const vq_f4 b = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, (cp.tab + en1 * 4u) * 4u, 0, 0));
             add[0] = a.x; add[1] = a.y; add[2] = a.z; add[3] = a.w;
             add[4] = b.x; add[5] = b.y; add[6] = b.z; add[7] = b.w;
           } else if (sh == 1u) {  // four vectors of 2
@@ -201,9 +205,8 @@ __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t 
             for (int k = 0; k < 4; ++k) en[k] = entry(i0 + k);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const bool ok = en[k] <= nent1;
-              bad_entry |= !ok;
-              const float2 a = *(const float2*)(pool + (ok ? cp.tab + en[k] * 2u : 0u));
+              bad_entry |= en[k] > nent1;
+              const vq_f2 a = __builtin_bit_cast(vq_f2, __builtin_amdgcn_raw_buffer_load_b64(pool, (cp.tab + en[k] * 2u) * 4u, 0, 0));
               add[2 * k] = a.x;
               add[2 * k + 1] = a.y;
             }
@@ -213,9 +216,8 @@ __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t 
             for (int k = 0; k < VQ_GROUP; ++k) en[k] = entry(e0 + w0 + k);
 #pragma unroll
             for (int k = 0; k < VQ_GROUP; ++k) {
-              const bool ok = en[k] <= nent1;
-              bad_entry |= !ok;
-              add[k] = pool[ok ? cp.tab + en[k] : 0u];
+              bad_entry |= en[k] > nent1;
+              add[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pool, (cp.tab + en[k]) * 4u, 0, 0));  // (the builtin returns the bits)
             }
           }
         } else {
@@ -224,7 +226,7 @@ __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t 
           for (int k = 0; k < VQ_GROUP; ++k) {
             const uint32_t idx = vq_general_index(X.type, X.psize, w0 + k, step, nent1, cp.tab, e0, ENT_LDS, s_ent + X.ent_shift, eg);
             bad_entry |= idx == 0xFFFFFFFFu;
-            add[k] = pool[idx == 0xFFFFFFFFu ? 0u : idx];
+            add[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pool, (idx == 0xFFFFFFFFu ? 0u : idx) * 4u, 0, 0));
           }
         }
 #pragma unroll
@@ -291,7 +293,8 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
   uint8_t* s_cls = s_raw + lo[5];
   uint8_t* s_chan = s_raw + lo[6];
   const VqBook* books = (const VqBook*)(vqb + VH->off_books);
-  const float* pool = (const float*)(vqb + VH->off_pool);
+  // the pool of value tables behind a buffer descriptor (raw buffer, no stride: offsets are bounds-checked against its byte size)
+  const __amdgpu_buffer_rsrc_t pool = __builtin_amdgcn_make_buffer_rsrc((void*)(vqb + VH->off_pool), 0, VH->pool_floats * 4u, 0x00020000);
   const uint32_t max_slots = VH->max_slots;
   uint32_t staged_residue = 0xFFFFFFFFu, staged_map = 0xFFFFFFFFu, staged_sub = 0xFFFFFFFFu;
   for (uint32_t p = blockIdx.x; p < P; p += gridDim.x) {
