@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define VSYN_ABI_VERSION 2 /* 2: + residue VQ stage (vsyn_attach_vq, vsyn_vq_batch), page-locked host buffers */
+#define VSYN_ABI_VERSION 3 /* 2: + residue VQ stage (vsyn_attach_vq, vsyn_vq_batch), page-locked host buffers; 3: + vsyn_pcm_abs_sum_host,
+                              vsyn_pcm_fetch_host, VSYN_SUBMIT_KEEP_PCM (additive; the feature taps no longer force the staged kernels) */
 
 #define VSYN_MAX_CHANNELS 32 /* floor_used is a 32-bit mask (reference: uint8_t audio_channels) */
 #define VSYN_MAX_POSTS 65    /* Vorbis I: 2 + 31 partitions x <=8 dims, capped at 65 by the spec */
