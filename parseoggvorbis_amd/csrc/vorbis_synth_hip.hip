@@ -74,6 +74,10 @@ struct DevBuf {  // grow-only device buffer
     p = nullptr;
     cap = 0;
   }
+  ~DevBuf() { release(); }  // (vsyn_destroy selects the device before the handle goes away)
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
 };
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
@@ -396,6 +400,7 @@ void vsyn_destroy(vsyn_handle* h) {
   h->ws_env.release(); h->ws_blk.release();
   h->st_pk.release(); h->st_seg.release(); h->st_ys.release(); h->st_fy.release(); h->st_res.release(); h->st_pcm.release();
   h->st_env.release(); h->st_blk.release(); h->st_emit.release();
+  h->st_sum.release(); h->st_conv.release(); h->st_frames.release();
   for (auto& ev : h->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
