@@ -383,6 +383,31 @@ def main():
             cpu = {"value": round(len(hp) * reps / t_cpu, 1), "unit": "packets/s", "cores": 1, "kind": "port",
                    "sample": "%d streams x %d packets of the same batch, oracle/liboracle.so (gcc -O2), %d repetitions, %.1f s"
                              % (ns, b["ppk"], reps, t_cpu)}
+            # the same port on every core of this process's share (packets of different streams are independent: one oracle
+            # instance per thread, the C calls release the GIL) — SURVEY 8d asks for the all-cores number beside the single-thread one
+            try:
+                import threading
+                ncores = max(1, min(16, os.cpu_count() or 1))
+                orcs = [OracleSynth(spec, ns) for _ in range(ncores)]
+                counts = [0] * ncores
+                t_end = time.perf_counter() + 4.0
+
+                def work(k):
+                    while time.perf_counter() < t_end:
+                        orcs[k].submit_host(hp, hs, hy, hr, b["plane"])
+                        counts[k] += 1
+
+                c0 = time.perf_counter()
+                th = [threading.Thread(target=work, args=(k,)) for k in range(ncores)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                t_all = time.perf_counter() - c0
+                cpu["all_cores"] = {"value": round(len(hp) * sum(counts) / t_all, 1), "unit": "packets/s", "cores": ncores, "kind": "port",
+                                    "sample": "%d threads, %d passes over the same sample in %.1f s" % (ncores, sum(counts), t_all)}
+            except Exception as exc:
+                cpu["all_cores"] = {"error": str(exc)[:200]}
             # the reference's own src/mdct.cpp, built from its sources into oracle/_ref (when present on this box): IMDCT only
             try:
                 from oracle import oracle_binding as ob
