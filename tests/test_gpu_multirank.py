@@ -13,7 +13,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
-def _run(extra, port):
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run(extra):
+    port = _free_port()
     env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
@@ -25,7 +33,7 @@ def _run(extra, port):
 
 
 def test_two_ranks_default_workload():
-    j = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline"], 29531)
+    j = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline"])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["packets_per_gpu"] == 65536
     # whole-job aggregate: both ranks' packets over the slower rank's clock
     assert abs(j["value"] - 2 * 65536 * 20 / (j["ms_per_step"] * 1e-3 * 20)) / j["value"] < 0.01
@@ -33,5 +41,5 @@ def test_two_ranks_default_workload():
 
 
 def test_two_ranks_real_files():
-    j = _run(["--steps", "1", "--warmup", "1", "--workload", "config5", "--files-per-gpu", "200", "--host-threads", "4"], 29532)
+    j = _run(["--steps", "1", "--warmup", "1", "--workload", "config5", "--files-per-gpu", "200", "--host-threads", "4"])
     assert j["n_gpus"] == 2 and j["config"]["packets_per_gpu"] == 200 * 94 and j["replicas_bit_identical"]
