@@ -28,8 +28,9 @@
 extern "C" {
 #endif
 
-#define VSYN_ABI_VERSION 3 /* 2: + residue VQ stage (vsyn_attach_vq, vsyn_vq_batch), page-locked host buffers; 3: + vsyn_pcm_abs_sum_host,
-                              vsyn_pcm_fetch_host, VSYN_SUBMIT_KEEP_PCM (additive; the feature taps no longer force the staged kernels) */
+#define VSYN_ABI_VERSION 4 /* 2: + residue VQ stage (vsyn_attach_vq, vsyn_vq_batch), page-locked host buffers; 3: + vsyn_pcm_abs_sum_host,
+                              vsyn_pcm_fetch_host, VSYN_SUBMIT_KEEP_PCM (additive; the feature taps no longer force the staged kernels);
+                              4: + vsyn_fused_paths (additive) */
 
 #define VSYN_MAX_CHANNELS 32 /* floor_used is a 32-bit mask (reference: uint8_t audio_channels) */
 #define VSYN_MAX_POSTS 65    /* Vorbis I: 2 + 31 partitions x <=8 dims, capped at 65 by the spec */
@@ -157,6 +158,10 @@ void vsyn_destroy(vsyn_handle* h);
 
 uint32_t vsyn_ys_stride(const vsyn_handle* h);           /* uint16 elements per (packet,channel) row of ys */
 uint32_t vsyn_channels(const vsyn_handle* h);
+/* Which synthesis kernels this handle's setup gets (diagnostics, tests): bit 0 = the fused kernel takes runs of long blocks,
+ * bit 1 = it also takes mixed-block runs and carry-ins; 0 = every batch goes through the staged (any-shape) kernels.
+ * Results are the same either way; only the speed differs. */
+uint32_t vsyn_fused_paths(const vsyn_handle* h);
 /* size in bytes of the constant block, and a copy of it (for the one RCCL broadcast of a multi-GPU job) */
 size_t vsyn_const_block_bytes(const vsyn_handle* h);
 

@@ -171,7 +171,7 @@ class SetupSpec:
 
 
 _SYMBOLS = [
-    "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels",
+    "vsyn_version", "vsyn_abi_version", "vsyn_create", "vsyn_destroy", "vsyn_ys_stride", "vsyn_channels", "vsyn_fused_paths",
     "vsyn_const_block_bytes", "vsyn_submit_device", "vsyn_submit_host", "vsyn_sync_status", "vsyn_reset_streams",
     "vsyn_profile_enable", "vsyn_profile_read", "vsyn_imdct_device", "vsyn_host_alloc", "vsyn_host_free",
     "vsyn_attach_vq", "vsyn_submit_device_vq", "vsyn_submit_host_vq", "vsyn_pcm_interleave_device", "vsyn_pcm_abs_sum_host", "vsyn_pcm_fetch_host",
@@ -212,6 +212,8 @@ def load():
     lib.vsyn_channels.restype = u32
     lib.vsyn_const_block_bytes.argtypes = [vp]
     lib.vsyn_const_block_bytes.restype = C.c_size_t
+    lib.vsyn_fused_paths.argtypes = [vp]
+    lib.vsyn_fused_paths.restype = u32
     lib.vsyn_submit_device.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, u64, vp, C.POINTER(Taps), u32, vp, cpp]
     lib.vsyn_submit_host.argtypes = [vp, u32, vp, u32, vp, vp, vp, C.c_size_t, vp, u64, vp, C.POINTER(Taps), u32,
                                      C.POINTER(Status), cpp]
@@ -259,6 +261,7 @@ class Synth:
         self.h = h
         self.channels = spec.channels
         self.ys_stride = self.lib.vsyn_ys_stride(h)
+        self.fused_paths = self.lib.vsyn_fused_paths(h)  # bit 0: fused kernel for long-block runs, bit 1: for mixed-block runs too
 
     def close(self):
         if getattr(self, "h", None):

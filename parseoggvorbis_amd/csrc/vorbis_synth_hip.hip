@@ -114,6 +114,8 @@ struct vsyn_handle {
   hipStream_t pre = nullptr;           // layout + floor unwrap of submit i+1 run beside the fused kernel of submit i
   hipEvent_t ev_join = nullptr, ev_pre_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr};
   bool main_done_valid[2] = {false, false};
+  bool pre_done_valid[2] = {false, false};
+  hipStream_t last_pre_stream = nullptr;  // stream the previous submit's layout kernel ran on (valid iff pre_done_valid[its half])
   uint32_t submit_count = 0;
   // workspace
   // per-batch workspace, double buffered by submit parity so that consecutive submits can overlap
@@ -378,6 +380,29 @@ void vsyn_destroy(vsyn_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+#ifdef VSYN_STAMPS
+  {  // diagnostic build: per-phase cycles of the LAST launch's steady runs, averaged over the waves that ran one
+    static unsigned long long host[8192][VSYN_NSTAMPS];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_vsyn_stamps), sizeof(host)) == hipSuccess) {
+      double sum[VSYN_NSTAMPS] = {0};
+      unsigned long long waves = 0, pk = 0;
+      for (int u = 0; u < 8192; ++u) {
+        if (!host[u][VSYN_NSTAMPS - 1]) continue;
+        ++waves;
+        pk += host[u][VSYN_NSTAMPS - 1];
+        for (int i = 0; i + 1 < VSYN_NSTAMPS; ++i) sum[i] += (double)host[u][i];
+      }
+      if (pk) {
+        static const char* nm[VSYN_NSTAMPS - 1] = {"loop", "residue+handoff+couple", "loads+floor setup", "floor product", "mirror+pre-rot", "partner wait 2",
+                                                   "fft512", "post+window+overlap", "stores"};
+        double tot = 0;
+        for (int i = 0; i + 1 < VSYN_NSTAMPS; ++i) tot += sum[i];
+        fprintf(stderr, "vsyn stamps: %llu waves, %llu wave-packets, %.0f cycles per wave-packet\n", waves, pk, tot / pk);
+        for (int i = 0; i + 1 < VSYN_NSTAMPS; ++i) fprintf(stderr, "  %-26s %8.0f cycles  %5.1f %%\n", nm[i], sum[i] / pk, 100.0 * sum[i] / tot);
+      }
+    }
+  }
+#endif
   fused_tables_destroy(&h->fused);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->pre) (void)hipStreamDestroy(h->pre);
@@ -410,6 +435,7 @@ void vsyn_destroy(vsyn_handle* h) {
 
 uint32_t vsyn_ys_stride(const vsyn_handle* h) { return h ? h->H.ys_stride : 0; }
 uint32_t vsyn_channels(const vsyn_handle* h) { return h ? h->H.channels : 0; }
+uint32_t vsyn_fused_paths(const vsyn_handle* h) { return h ? h->fused_mask : 0; }
 size_t vsyn_const_block_bytes(const vsyn_handle* h) { return h ? h->host_const.size() : 0; }
 
 int vsyn_profile_enable(vsyn_handle* h, int on) {
@@ -535,6 +561,10 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged;
   hipStream_t ps = overlap_pre ? h->pre : s;
   if (h->main_done_valid[wb]) HIPCHK(hipStreamWaitEvent(ps, h->ev_main_done[wb], 0));
+  // The layout kernels of consecutive submits chain through the stream state (abs position, carry parity) and the list-counter
+  // ring: when this submit's pre-kernels run on another stream than the previous submit's did (flags differ between submits),
+  // that order has to be stated.
+  if (h->pre_done_valid[wb ^ 1u] && h->last_pre_stream != ps) HIPCHK(hipStreamWaitEvent(ps, h->ev_pre_done[wb ^ 1u], 0));
   {
     // (a 1024-thread block cannot sit next to a synthesis workgroup: it pays only when the serial scan of a very long segment
     //  would otherwise dominate — 1 x 65536 packets: 105 -> 128 M packets/s, but 16 x 4096: 221 -> 191 M)
@@ -557,6 +587,8 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   }
   if (d_vq && h->profile_which == 3) HIPCHK(profile_end(h, ps));
   HIPCHK(hipEventRecord(h->ev_pre_done[wb], ps));
+  h->pre_done_valid[wb] = true;
+  h->last_pre_stream = ps;
   if (ps != s) HIPCHK(hipStreamWaitEvent(s, h->ev_pre_done[wb], 0));
 
   // staged kernels walk the work list the layout kernel built: everything when forced, otherwise only the runs the

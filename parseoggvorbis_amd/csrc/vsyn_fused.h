@@ -29,6 +29,29 @@
 #define FUSED_MIN_WAVES_PER_SIMD 4
 #endif
 #define FUSED_XSLOTS 576  // float2 slots of the per-wave exchange image: 8 rows x 72 (>= 8 x 65)
+// Diagnostic builds only (tools/ab_variants.sh): -DVSYN_KNOCKOUT=<bits> removes one phase of the long-block loop so that its
+// marginal cost can be timed (the results are then wrong by construction): 1 channel hand-off + coupling, 2 floor product,
+// 4 FFT, 8 PCM stores, 16 floor set-up, 32 window/overlap arithmetic.
+#ifndef VSYN_KNOCKOUT
+#define VSYN_KNOCKOUT 0
+#endif
+// -DVSYN_STAMPS: per-phase cycle counts of the steady long-block loop (s_memtime at phase boundaries, which also drains the
+// wave's LDS queue there: phases no longer overlap each other, so the sum exceeds the unstamped iteration). Read back and
+// printed by vsyn_destroy. Diagnostic builds only.
+#ifdef VSYN_STAMPS
+#define VSYN_NSTAMPS 10
+__device__ unsigned long long g_vsyn_stamps[8192][VSYN_NSTAMPS];
+#define STAMP(i)                                                  \
+  do {                                                            \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    const unsigned long long t_ = __builtin_readcyclecounter();   \
+    st_acc[i] += t_ - st_last;                                    \
+    st_last = t_;                                                 \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // Read-only LDS image of the fused kernel, built once per handle on the host in exactly the order the lanes read
 // it (every table is lane-major: lane l of a wave-instruction reads element [..][l], so all reads are conflict-free).
@@ -101,6 +124,40 @@ __device__ __forceinline__ void dft8(float2 (&x)[8]) {
   x[7] = csub(d1, d3);
 }
 
+// Register-to-register forms of the two index exchanges (no LDS): a transposition of three register-index bits with three
+// lane bits is three swap stages; lane bits 5 and 4 have swap instructions (v_permlane32_swap / v_permlane16_swap), lane bits
+// 3 and 2 are DPP row shifts under a bank mask, lane bits 1 and 0 a DPP quad permutation plus a select.
+typedef unsigned xch_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void xch_swap32(float& a, float& b) {  // a[32..63] <-> b[0..31]
+  const xch_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void xch_swap16(float& a, float& b) {  // odd rows of a <-> even rows of b
+  const xch_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+template <int SH>  // lane bit 3 (SH = 8) or 2 (SH = 4)
+__device__ __forceinline__ void xch_row(float& lo, float& hi) {
+  constexpr int shr = 0x110 + SH, shl = 0x100 + SH;
+  constexpr int up = SH == 8 ? 0xC : 0xA, dn = SH == 8 ? 0x3 : 0x5;
+  const unsigned l = __float_as_uint(lo), h = __float_as_uint(hi);
+  const unsigned nl = __builtin_amdgcn_update_dpp(l, h, shr, 0xF, up, false);  // lanes with the bit set: hi of lane - SH
+  const unsigned nh = __builtin_amdgcn_update_dpp(h, l, shl, 0xF, dn, false);  // lanes with the bit clear: lo of lane + SH
+  lo = __uint_as_float(nl);
+  hi = __uint_as_float(nh);
+}
+template <int BIT>  // lane bit 1 or 0
+__device__ __forceinline__ void xch_quad(float& lo, float& hi, bool bitset) {
+  constexpr int qp = BIT == 1 ? 0x4E : 0xB1;
+  const unsigned l = __float_as_uint(lo), h = __float_as_uint(hi);
+  const unsigned th = __builtin_amdgcn_mov_dpp(h, qp, 0xF, 0xF, false);
+  const unsigned tl = __builtin_amdgcn_mov_dpp(l, qp, 0xF, 0xF, false);
+  lo = __uint_as_float(bitset ? th : l);
+  hi = __uint_as_float(bitset ? h : tl);
+}
+
 // FFT-512 across one wave: in: lane l holds z[t] = point l + 64 t; out: lane l holds Z[c'] = bin swap3(l) + 64 c'.
 // xb = this wave's exchange image (FUSED_XSLOTS float2), w = W512^j table (LDS).
 __device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__ xb, const FusedLdsImage* __restrict__ T, uint32_t lane) {
@@ -109,20 +166,49 @@ __device__ __forceinline__ void fft512_wave(float2 (&z)[8], float2* __restrict__
 #pragma unroll
   for (int t = 1; t < 8; ++t) z[t] = cmulf(z[t], T->tw1[t][lane]);
   // exchange 1: element (t', a, c): lane 8a+c reg t'  ->  lane 8t'+c reg a.   row stride 72: conflict-free both ways
+#if defined(VSYN_FFT_REGS) && (VSYN_FFT_REGS & 1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { xch_swap32(z[i].x, z[i + 4].x); xch_swap32(z[i].y, z[i + 4].y); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) if (!(i & 2)) { xch_swap16(z[i].x, z[i + 2].x); xch_swap16(z[i].y, z[i + 2].y); }
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) { xch_row<8>(z[i].x, z[i + 1].x); xch_row<8>(z[i].y, z[i + 1].y); }
+#else
 #pragma unroll
   for (int t = 0; t < 8; ++t) xb[t * 72 + lane] = z[t];
 #pragma unroll
   for (int a = 0; a < 8; ++a) z[a] = xb[hi * 72 + a * 8 + c];
+#endif
   dft8(z);  // over a -> a'
 #pragma unroll
   for (int a = 1; a < 8; ++a) z[a] = cmulf(z[a], T->tw2[a][c]);  // W64^(c a')
   // exchange 2: element (h, a', c): lane 8h+c reg a'  ->  lane 8h+a' reg c.   row stride 65
+#if defined(VSYN_FFT_REGS) && (VSYN_FFT_REGS & 2)
+  {
+    const bool b1 = (lane & 2u) != 0, b0 = (lane & 1u) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xch_row<4>(z[i].x, z[i + 4].x); xch_row<4>(z[i].y, z[i + 4].y); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (!(i & 2)) { xch_quad<1>(z[i].x, z[i + 2].x, b1); xch_quad<1>(z[i].y, z[i + 2].y, b1); }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) { xch_quad<0>(z[i].x, z[i + 1].x, b0); xch_quad<0>(z[i].y, z[i + 1].y, b0); }
+  }
+#else
 #pragma unroll
   for (int a = 0; a < 8; ++a) xb[a * 65 + lane] = z[a];
 #pragma unroll
   for (int k = 0; k < 8; ++k) z[k] = xb[c * 65 + hi * 8 + k];
+#endif
   dft8(z);  // over c -> c'
 }
+
+// The compiler's wait-count insertion merges conservatively where control flow joins: a vector load in a RARE branch (floor
+// change, re-read of a coded row) right before a join makes every later use of ANY loaded register wait for vmcnt(0) — which,
+// inside the packet loop, means waiting for the residue prefetch that was issued a few instructions earlier and for the PCM
+// stores of the previous packet (measured with -DVSYN_STAMPS: a third of the loop's cycles). Rare branches therefore finish
+// their own loads before they rejoin, and so does the loop's prologue: the joins then only carry the steady state's order
+// (row of packet q+1, PCM stores of q, residue of q+1) and the waits inside the loop are the counted ones.
+__device__ __forceinline__ void vmem_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // gfx9 encoding: vmcnt(0), expcnt/lgkmcnt untouched
 
 // hpp:1220-1239, branch-free (selects only; same comparisons, same single add/sub per output, so bit-identical):
 //   d = m > 0 ? a : -a;   a > 0 ? (M, A) = (m, m - d) : (M, A) = (m + d, m)
@@ -287,6 +373,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     }
   }
   uint32_t lane_v = lane0;
+  vmem_drain();  // see vmem_drain(): the loop must not inherit "the residue registers were loaded last" from here
+#ifdef VSYN_STAMPS
+  unsigned long long st_acc[VSYN_NSTAMPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_readcyclecounter();
+#endif
   // The two waves of a coupled channel pair (adjacent waves, same run, same packets) each load ONLY their own channel
   // from HBM and hand it to the partner through their exchange image, which is idle at that point: loading both channels
   // in both waves costs a second HBM fetch of the whole input (measured: concurrent misses on a line are not merged;
@@ -294,6 +385,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   // my_flags[1] = "I have read the partner's image of packet #n".
   for (uint32_t it = 0; q0 + it < qb; ++it) {
     const uint32_t q = q0 + it;
+    STAMP(0);  // loop overhead / previous iteration's tail
     // launder the lane id once per packet: keeps the lane-derived LDS/global addresses from being hoisted out of
     // the loop and pinned in VGPRs for its whole duration (recomputing them costs a few VALU ops)
     asm volatile("" : "+v"(lane_v));
@@ -333,7 +425,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         for (int t = 0; t < 8; ++t)
           if (t == 0 || L) raw[t] = src[64 * t];
       }
-      if (ROLE != 0) {
+      if (ROLE != 0 && !(VSYN_KNOCKOUT & 1)) {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
           if (t == 0 || L) xb[t * 64 + lane] = raw[t];
@@ -343,7 +435,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         if (t != 0 && !L) continue;
-        if (ROLE == 0) {
+        if (ROLE == 0 || (VSYN_KNOCKOUT & 1)) {
           r[t] = raw[t];
         } else {
           const float2 oth = pxb[t * 64 + lane];
@@ -354,7 +446,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     };
     if (lng) residue_rows(true);
     else residue_rows(false);
-    if (ROLE != 0) pair_post(&my_flags[1], it + 1);
+    STAMP(1);  // residue arrival (vmcnt), hand-off through LDS, partner wait, coupling
+    if (ROLE != 0 && !(VSYN_KNOCKOUT & 1)) pair_post(&my_flags[1], it + 1);
     // `raw` is dead: request packet q+1 now, so that its 4 KiB stay in flight behind this packet's floor product, FFT and
     // overlap (memory-level parallelism bounded this kernel, not occupancy). Unconditional on purpose: on a run's last
     // packet the current block is re-read (cache-resident, 1/R of the loads) — a `has_next` guard lets the compiler fold
@@ -369,7 +462,9 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     // ---- floor-1 step 2 set-up: one table entry per sorted-post interval (hpp:563-584) ---------------------
     bool floor_bad = false;
     float2* const seg2 = (float2*)seg;  // this kernel's entries are 8 bytes: table index = floor(x * e.x + e.y)
-    if (!((pi.own >> c) & 1u)) {
+    if (VSYN_KNOCKOUT & 16) {
+      if (it == 0) seg2[lane] = f2(0.f, 200.5f);
+    } else if (!((pi.own >> c) & 1u)) {
       // no curve of its own: one constant entry. Not used at all -> index 255 (table value exactly 1.0f, x*1 == x);
       // used through the coupling propagate -> index 256 (0.0f: floor_outputs stays zero, hpp:1159,1176-1179)
       seg2[lane] = f2(0.f, ((pi.used >> c) & 1u) ? 256.5f : 255.5f);
@@ -391,8 +486,10 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         xsl = in ? fc->xs_sorted[lane] : 0u;
         cur_floor = (int)f;
         v = row[sidx];
+        vmem_drain();
       } else if (!vrow_ok) {
         v = row[sidx];
+        vmem_drain();
       }
       if (lane >= posts) v = 0;
       const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
@@ -418,6 +515,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       const float a = ady * inv, b = __builtin_fmaf(-ady, x0, 0.5f) * inv;
       seg2[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);
     }
+    STAMP(2);  // next packet's loads issued, floor set-up (coded row arrival, ballot, two bpermutes, entry write)
     // coded posts of packet q+1, one packet ahead (valid if the floor does not change)
     vrow_ok = has_next && pin.mapping == pi.mapping && cur_floor >= 0;
     vrow = (A.fy + ((size_t)(has_next ? p + 1 : p) * C + c) * ys_stride)[sidx];
@@ -473,7 +571,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     // through the carry image; at the end of the run the next run's wave recomputes this block as its halo)
     const bool hand_over = MIXED && has_next && !pin.bad && (nlng != lng);
     if (lng) {
-      floor_product(true);
+      if (!(VSYN_KNOCKOUT & 2)) floor_product(true);
+      STAMP(3);  // floor curve look-ups + product
       // ---- IMDCT: mirror exchange, pre-rotation, FFT-512, post-rotation -------------------------------------
       float2 z[8];
 #pragma unroll
@@ -481,14 +580,17 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         const float im = __shfl(r[7 - t].y, 63 - (int)lane);  // X[1023 - 2k] lives in the mirror lane, slot 7-t
         z[t] = cmulf(f2(r[t].x, im), T.pre[t][lane]);
       }
-      if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT may reuse it
+      STAMP(4);  // mirror exchange + pre-rotation
+      if (ROLE != 0 && !(VSYN_KNOCKOUT & 1)) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the FFT may reuse it
+      STAMP(5);  // second partner wait
 #ifdef VSYN_EXP_SETPRIO
       __builtin_amdgcn_s_setprio(VSYN_EXP_SETPRIO);
 #endif
-      fft512_wave(z, xb, &T, lane);
+      if (!(VSYN_KNOCKOUT & 4)) fft512_wave(z, xb, &T, lane);
 #ifdef VSYN_EXP_SETPRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
+      STAMP(6);  // FFT-512
 #pragma unroll
       for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post[k][lane]);
 
@@ -569,8 +671,18 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         n_s[j] = __shfl(ol_s, 63 - (int)lane);
         n_m[j] = __shfl(ol_m, 63 - (int)lane);
       }
+      // Everything this wave has in flight here is LOADS issued long ago (residue and coded row of packet q+1): finish them before
+      // the PCM stores go out, so that no later wait in the loop (the compiler places the loop-carried copies of those registers
+      // behind the stores, where only vmcnt(0) is safe on every path) ever waits for a store. The stores are never waited for.
+      vmem_drain();
+      STAMP(7);  // post-rotation, window reads, overlap arithmetic, mirror exchange of the outputs
       // sample s = 2*kappa + 128*j of (lane, kh = 4 + j): two lane pointers, every store at an immediate offset
-      if (fast_store) {
+      if (VSYN_KNOCKOUT & 8) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += oh_s[j] + n_s[j] + n_m[j] + oh_m[j];
+        if (acc == 12345.678f) out[lane] = acc;  // keeps the arithmetic alive without the stores
+      } else if (fast_store) {
         float* up = out + 2u * kappa;            // samples s, s+1
         float* dn = out + 1022u - 2u * kappa;    // samples 1022-s, 1023-s
 #pragma unroll
@@ -590,6 +702,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
           if (f3m < emit) out[f3m] = oh_m[j];
         }
       }
+      STAMP(8);  // PCM stores issued
       if (last_of_segment || hand_over) {
         // the windowed right half in natural order: sample s of point k at position s.  Last block of the segment: all of it
         // into the stream's carry buffer for the next submit.  Before a short block: frames 0..447 are final (nothing else
@@ -620,6 +733,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
             }
           }
         }
+        vmem_drain();  // rare block: rejoin with nothing of its own pending (see vmem_drain)
       }
     } else {
       // ---- short block: one complex point per lane ------------------------------------------------------------
@@ -670,10 +784,20 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       prev_half = M;  // (registers of the other size are never consulted: a size change always goes through K_LDS, and a
                       //  skipped packet clears both)
     }
-    if (__any(floor_bad) && lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
+    if (__any(floor_bad)) {
+      if (lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
+      vmem_drain();
+    }
     prev_next_long = cur_next_long;
     pi = pin;
   }
+#ifdef VSYN_STAMPS
+  if (!MIXED && lane0 == 0) {
+    const uint32_t unit = blockIdx.x * FUSED_WAVES + (threadIdx.x >> 6);
+    if (unit < 8192)
+      for (int i = 0; i < VSYN_NSTAMPS; ++i) g_vsyn_stamps[unit][i] = i == VSYN_NSTAMPS - 1 ? (unsigned long long)(qb - q0) : st_acc[i];
+  }
+#endif
 }
 
 static_assert(FUSED_WAVES % 2 == 0, "the two channel waves of a run must share a workgroup");

@@ -255,6 +255,10 @@ struct Feeder {
     for (uint32_t s = 0; s < S; ++s) {
       const PacketBatch& b = g.pending[s]->batch;
       CHECK(b.vq == g.vq);
+      // the staging arrays were sized from pk / residue_floats: a batch whose per-packet vectors disagree with them (a packet
+      // that failed half way and was not rolled back) must not be copied
+      CHECK(b.ys.size() == b.pk.size() * C * g.ys_stride);
+      CHECK(b.vq || b.residue.size() == b.residue_floats);
       memcpy(&g.pk[p0], b.pk.data(), b.pk.size() * sizeof(vsyn_packet));
       memcpy(&g.ys[p0 * C * g.ys_stride], b.ys.data(), b.ys.size() * sizeof(uint16_t));
       if (g.vq) {

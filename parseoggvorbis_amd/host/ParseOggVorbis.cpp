@@ -856,6 +856,24 @@ OkOrError VorbisStream::parse_audio(const uint8_t* data, uint32_t len, int64_t g
   }
   const uint32_t n = mode.blocksize, n2 = n / 2;
 
+  // A packet that fails half way (a CHECK below) must leave the batch as it found it: the rows and entries it already appended
+  // would otherwise make ys_ / residue_ / cls_ / entries_ longer than pk_ accounts for, and whoever packs the batch next
+  // (flush, CorpusDecoder's feeders) sizes its buffers from pk_.
+  struct Rollback {
+    VorbisStream& s;
+    const size_t ys, fl, res, cls, ent;
+    bool armed = true;
+    explicit Rollback(VorbisStream& st) : s(st), ys(st.ys_.size()), fl(st.floor_number_.size()), res(st.residue_.size()), cls(st.cls_.size()), ent(st.entries_.size()) {}
+    ~Rollback() {
+      if (!armed) return;
+      s.ys_.resize(ys);
+      s.floor_number_.resize(fl);
+      s.residue_.resize(res);
+      s.cls_.resize(cls);
+      s.entries_.resize(ent);
+    }
+  } rollback(*this);
+
   // 4.3.2 floor curve decode: only the coded Y values; the curve is rendered on the GPU
   const size_t row0 = ys_.size();
   ys_.resize(row0 + (size_t)C * ys_stride_, 0);
@@ -919,6 +937,7 @@ OkOrError VorbisStream::parse_audio(const uint8_t* data, uint32_t len, int64_t g
   pk.floor_used = own_mask;
   pk.granule = granule;
   pk_.push_back(pk);
+  rollback.armed = false;  // the packet is complete: it belongs to the batch now
   if (pk_.size() >= batch_limit_) CHECK_ERR(flush(cb));
   return OkOrError();
 }
@@ -1059,7 +1078,12 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
         chans[ch] = DataRange<const float>(&pcm[(size_t)ch * plane + out_off], frames);
         if (hooks) push_data_float(this, "pcm", (int)ch, chans[ch].begin(), frames);
       }
-      CHECK(cb.gotPcmData(chans));
+      if (!cb.gotPcmData(chans)) {  // the sink asked to stop (hpp:1053): drop the rest of the batch, so that nothing is replayed twice
+        pk_.clear(); ys_.clear(); residue_.clear(); floor_number_.clear(); vq_pk_.clear(); cls_.clear(); entries_.clear();
+        residue_floats_ = 0;
+        first_batch_ = false;
+        CHECK(false && "gotPcmData returned false");
+      }
       abs_total_pos_ += frames;
       out_off += frames;
     }
@@ -1162,7 +1186,16 @@ OkOrError OggReader::read_next_page(bool& reached_eof) {
 
 OkOrError OggReader::read_until_end() {
   bool eof = false;
-  while (!eof) CHECK_ERR(read_next_page(eof));
+  while (!eof) {
+    const OkOrError r = read_next_page(eof);
+    if (r.is_error_) {
+      // Upstream hands out PCM packet by packet, so everything before the failing packet has reached gotPcmData and the hooks
+      // when its CHECK fires (hpp:1045-1054). Here those packets may still sit in a batch (the failing one was rolled back by
+      // parse_audio): synthesise and deliver them, then report the original error.
+      for (auto& kv : streams_) (void)kv.second->flush(callbacks_);
+      return r;
+    }
+  }
   for (auto& kv : streams_) CHECK_ERR(kv.second->flush(callbacks_));  // streams without an end-of-stream page
   return OkOrError();
 }

@@ -15,6 +15,60 @@ def shard_range(num_items, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
+def stream_positions(spec, packets, abs0=0):
+    """Host restatement of the stream bookkeeping (reference hpp:1019-1067, what the layout kernel scans on the device) for ONE
+    stream starting at absolute position abs0 with no block before it: -> (abs_before [P], emit [P]) as int64.
+    L_q = n_{q-1}/4 + n_q/4 (0 for the first packet); abs_after_q = granule_q if granule_q >= 0 else abs_before_q + L_q."""
+    P = len(packets)
+    n = np.where(np.asarray([spec.modes[int(m)][0] for m in packets["mode"]], bool), spec.blocksize1, spec.blocksize0).astype(np.int64)
+    L = np.zeros(P, np.int64)
+    L[1:] = n[:-1] // 4 + n[1:] // 4
+    gran = packets["granule"].astype(np.int64)
+    has = gran >= 0
+    # abs_after[q] = granule of the last packet j <= q that carries one, plus the natural frames after it
+    idx = np.where(has, np.arange(P), -1)
+    last = np.maximum.accumulate(idx)
+    cl = np.cumsum(L)
+    base = np.where(last >= 0, gran[np.maximum(last, 0)] - cl[np.maximum(last, 0)], abs0)
+    abs_after = base + cl
+    abs_before = np.concatenate([[abs0], abs_after[:-1]])
+    return abs_before, abs_after - abs_before
+
+
+def shard_packets(spec, batch, rank, world):
+    """Second partitioning of SURVEY 8e: ONE long stream cut into contiguous packet ranges, one per rank, no communication.
+    Packet p depends on p-1 only through the overlap-add (hpp:1008-1017, 1061-1109), so a rank re-decodes the last packet of
+    its left neighbour's range (a one-packet halo) and drops that packet's output: its segment starts at the halo with
+    VSYN_SEG_RESET — the first block of a stream emits nothing (hpp:1021-1027) — and the page granules are rebased to the
+    segment's own origin. The concatenation of the ranks' PCM is the unsharded PCM, bit for bit (same blocks, same sums).
+
+    batch: a ONE-segment batch (dict packets/segments/ys/residue/plane_stride as tests.workloads.synth_batch makes it) whose
+    segment starts its stream. -> dict with the rank's batch (packets, segments, ys, residue, plane_stride) plus
+    `first`, `count` (its packets of the original stream), `halo` (0 or 1 leading packets whose output is dropped) and
+    `frame_offset` (absolute position of its first emitted frame)."""
+    from .binding import VSYN_SEG_RESET
+    assert len(batch["segments"]) == 1
+    pk_all = batch["packets"]
+    P = len(pk_all)
+    C = spec.channels
+    first, count = shard_range(P, rank, world)
+    halo = 1 if (first > 0 and count > 0) else 0
+    lo, hi = first - halo, first + count
+    n = np.where(np.asarray([spec.modes[int(m)][0] for m in pk_all["mode"]], bool), spec.blocksize1, spec.blocksize0).astype(np.int64)
+    res_off = int(batch["segments"][0]["residue_off"]) + np.concatenate([[0], np.cumsum(C * (n // 2))])
+    abs_before, _ = stream_positions(spec, pk_all)
+    pk = pk_all[lo:hi].copy()
+    origin = int(abs_before[first]) if count else 0  # the halo emits nothing: the segment's frame 0 is the first frame of packet `first`
+    if halo:
+        pk["granule"][0] = -1  # its page end belongs to the left neighbour
+    g = pk["granule"].astype(np.int64)
+    pk["granule"] = np.where(g >= 0, g - origin, -1)
+    seg = batch["segments"][:1].copy()
+    seg[0] = (0, 0, hi - lo, VSYN_SEG_RESET, 0)
+    return dict(packets=pk, segments=seg, ys=batch["ys"][lo:hi], residue=batch["residue"][int(res_off[lo]):int(res_off[hi])],
+                plane_stride=max(int(count) * (spec.blocksize1 // 2), 1) + 64, first=first, count=count, halo=halo, frame_offset=origin)
+
+
 def encode_spec(spec):
     """SetupSpec -> flat int32 vector (what rank 0 broadcasts)."""
     v = [spec.channels, spec.blocksize0, spec.blocksize1, len(spec.floors), len(spec.mappings), len(spec.modes)]

@@ -349,3 +349,116 @@ def test_feature_taps_from_the_fused_kernel(pattern, C):
     gpu.reset()
     plain = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
     assert np.array_equal(bits(plain["pcm"]), bits(got["pcm"]))  # the tap changes nothing else
+
+
+# ---- the fused path at its limits (hpp:484-492 multipliers/ranges, hpp:521-589 floor decode) -----------------------------------
+def _limit_spec(C, posts_long, mult_long, mult_short, coupled, posts_short=9, seed=5):
+    """256/2048 setup whose long-block floor has `posts_long` posts at random distinct x (header order shuffled, x[0] = 0 and
+    x[1] = n/2 as the format requires) and the given multipliers."""
+    rng = np.random.default_rng(seed)
+
+    def xs(n2, posts):
+        inner = rng.choice(np.arange(1, n2), posts - 2, replace=False) if posts > 2 else np.zeros(0, np.int64)
+        return [0, n2] + [int(v) for v in inner]
+    coup = [(0, 1)] if (coupled and C >= 2) else []
+    return SetupSpec(C, 256, 2048, [(mult_short, xs(128, posts_short)), (mult_long, xs(1024, posts_long))],
+                     [(coup, [0] * C), (coup, [1] * C)], [(0, 0), (1, 1)])
+
+
+LIMITS = [
+    # C, posts_long, mult_long, mult_short, coupled, pattern, fused paths expected (vsyn_fused_paths)
+    (2, 64, 2, 4, True, "long", 3),    # the most posts one ballot covers
+    (2, 64, 1, 3, True, "mixed", 3),   # ... with multipliers 1 and 3 (ranges 256 and 86)
+    (2, 2, 1, 1, True, "mixed", 3),    # the fewest: one segment per block, both floors
+    (1, 33, 3, 2, False, "mixed", 3),  # mono, multiplier 3 on the long floor
+    (2, 40, 4, 1, False, "mixed", 3),  # stereo WITHOUT a coupling step
+    (2, 17, 2, 2, False, "long", 3),
+    (2, 65, 2, 4, True, "mixed", 0),   # 65 posts: beyond the fused kernel's one-ballot floor set-up -> staged kernels
+]
+
+
+@pytest.mark.parametrize("C,posts,ml,ms,coupled,pattern,paths", LIMITS)
+def test_fused_path_limits(C, posts, ml, ms, coupled, pattern, paths):
+    """Floors with 2 / 64 / 65 posts, every multiplier, with and without coupling: the run class is asserted (so a silent fall
+    back to the staged kernels cannot pass for the fused path), posts and PCM against the oracle, and the fused kernel against
+    the staged kernels bit for bit where both exist."""
+    posts_short = 2 if posts == 2 else 9
+    spec = _limit_spec(C, posts, ml, ms, coupled, posts_short)
+    b = synth_batch(spec, 3, 37, pattern, seed=posts * 7 + ml, unused_frac=0.1, granule_last=True, ylo=20, yhi=70)
+    gpu = binding.Synth(spec, max_streams=3)
+    assert gpu.fused_paths == paths, (gpu.fused_paths, paths)
+    want = ob.OracleSynth(spec, 3).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
+    got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps="features")
+    check(got, want)
+    assert np.array_equal(got["taps"]["floor_final"], want["taps"]["floor_final"])
+    assert np.array_equal(got["taps"]["floor_curve"], want["taps"]["floor_curve"])
+    gpu.reset()
+    plain = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert np.array_equal(bits(plain["pcm"]), bits(got["pcm"]))
+    gpu.reset()
+    staged = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED)
+    check(staged, want)
+
+
+@pytest.mark.parametrize("pattern", ["long", "mixed"])
+def test_absolute_gate_at_unit_peak(pattern):
+    """The north-star gate as stated: |pcm - reference| < 1e-5 ABSOLUTE on a batch with |pcm| <= 1 (compare-debug-out.py:90)."""
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, 4, 48, pattern, seed=77, ylo=20, yhi=74)
+    want = ob.OracleSynth(spec, 4).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    peak = float(np.abs(want["pcm"]).max())
+    assert 0.05 < peak <= 1.0, peak
+    for flags in PATHS:
+        got = binding.Synth(spec, max_streams=4).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=flags)
+        err = check(got, want, scale_tol=False)
+        assert err < TOL, "max |err| %.3g at peak %.3f" % (err, peak)
+
+
+def test_submit_flags_may_alternate_between_submits():
+    """vsyn_submit_device with and without VSYN_SUBMIT_INPUTS_READY in turn, on continuing streams, with work queued on the caller's
+    stream in front: the layout kernels of consecutive submits chain through the stream state whichever stream they run on."""
+    import torch
+    spec = fixture_like_spec(2)
+    S, ppk, parts = 4, 24, 6
+    b = synth_batch(spec, S, ppk * parts, "mixed", seed=5)
+    orc = ob.OracleSynth(spec, S)
+    want = orc.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    gpu = binding.Synth(spec, max_streams=S)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_of = np.where(b["packets"]["mode"] == 1, spec.blocksize1, spec.blocksize0).reshape(S, ppk * parts)
+    keep = []
+    busy = torch.zeros(64 << 20, device="cuda")
+    for k in range(parts):
+        pk = np.concatenate([b["packets"][s * ppk * parts + k * ppk: s * ppk * parts + (k + 1) * ppk] for s in range(S)])
+        ys = np.concatenate([b["ys"][s * ppk * parts + k * ppk: s * ppk * parts + (k + 1) * ppk] for s in range(S)])
+        seg = b["segments"].copy()
+        res_parts, off = [], 0
+        for s in range(S):
+            base = int(b["segments"][s]["residue_off"]) + int(2 * (n_of[s, :k * ppk] // 2).sum())
+            ln = int(2 * (n_of[s, k * ppk:(k + 1) * ppk] // 2).sum())
+            res_parts.append(b["residue"][base:base + ln])
+            seg[s] = (s, s * ppk, ppk, binding.VSYN_SEG_RESET if k == 0 else 0, off)
+            off += ln
+        d = dict(pk=torch.from_numpy(pk.view(np.uint8)).cuda(), seg=torch.from_numpy(seg.view(np.uint8)).cuda(),
+                 ys=torch.from_numpy(ys.astype(np.int16)).cuda(), res=torch.from_numpy(np.concatenate(res_parts)).cuda(),
+                 pcm=torch.zeros((S, 2, ppk * 1024 + 64), device="cuda"), emit=torch.zeros(S * ppk, dtype=torch.int32, device="cuda"))
+        keep.append(d)
+    torch.cuda.synchronize()
+    for k, d in enumerate(keep):
+        for _ in range(4):
+            busy.add_(1.0)  # delayed work in front of the submit on the caller's stream
+        gpu.submit_device(S * ppk, d["pk"].data_ptr(), S, d["seg"].data_ptr(), ppk, d["ys"].data_ptr(), d["res"].data_ptr(),
+                          d["pcm"].data_ptr(), ppk * 1024 + 64, d["emit"].data_ptr(), None,
+                          binding.VSYN_SUBMIT_INPUTS_READY if k % 2 else 0, stream)
+    fl, bad = gpu.sync_status(stream)
+    assert fl == 0, (fl, bad)
+    emit_want = want["emit_len"].reshape(S, parts, ppk)
+    for s in range(S):
+        at = 0
+        for k, d in enumerate(keep):
+            e = d["emit"].cpu().numpy().astype(np.uint32).reshape(S, ppk)[s]
+            assert np.array_equal(e, emit_want[s, k])
+            n = int(e.sum())
+            got = d["pcm"][s, :, :n].cpu().numpy()
+            assert np.abs(got - want["pcm"][s][:, at:at + n]).max() < TOL * max(1.0, float(np.abs(want["pcm"]).max())), (s, k)
+            at += n

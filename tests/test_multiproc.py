@@ -79,3 +79,67 @@ def test_spec_codec_roundtrip():
     assert (back.channels, back.blocksize0, back.blocksize1) == (spec.channels, spec.blocksize0, spec.blocksize1)
     assert [(m, list(x)) for m, x in back.floors] == [(m, list(x)) for m, x in spec.floors]
     assert back.mappings[0][0] == spec.mappings[0][0] and list(back.modes) == [tuple(m) for m in spec.modes]
+
+
+# ---- second partitioning: packet ranges of ONE long stream, one-packet halo, no communication -----------------------
+LONG_PPK = 61
+
+
+def _long_stream(spec):
+    b = synth_batch(spec, 1, LONG_PPK, "mixed", seed=123, granule_last=True)
+    # page granules inside the stream too (every 7th packet ends a page), consistent with the block sizes
+    abs_before, emit = sharding.stream_positions(spec, b["packets"])
+    for q in range(6, LONG_PPK - 1, 7):
+        b["packets"]["granule"][q] = int(abs_before[q] + emit[q])
+    return b
+
+
+def _range_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle_binding import OracleSynth
+        dev = torch.device("cpu")
+        spec = sharding.broadcast_spec(fixture_like_spec(2) if rank == 0 else fixture_like_spec(1, 64, 64), dev, src=0)
+        sh = sharding.shard_packets(spec, _long_stream(spec), rank, world)
+        r = OracleSynth(spec, 1).submit_host(sh["packets"], sh["segments"], sh["ys"], sh["residue"], sh["plane_stride"])
+        assert r["rc"] == 0, r["flags"]
+        assert int(r["emit_len"][:sh["halo"]].sum()) == 0  # the halo's output is dropped by construction
+        frames = int(r["emit_len"].sum())
+        _, units, (total,) = sharding.aggregate(0.0, sh["count"], dev, extra_sum=(frames,))
+        assert units == LONG_PPK
+        np.savez(os.path.join(out_dir, "range%d.npz" % rank), pcm=r["pcm"][0][:, :frames], offset=sh["frame_offset"], total=total,
+                 emit=r["emit_len"][sh["halo"]:])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_packet_range_sharding_matches_unsharded_bit_for_bit(tmp_path, world):
+    mp.spawn(_range_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle.oracle_binding import OracleSynth
+    spec = fixture_like_spec(2)
+    full = _long_stream(spec)
+    want = OracleSynth(spec, 1).submit_host(full["packets"], full["segments"], full["ys"], full["residue"], full["plane_stride"])
+    assert want["rc"] == 0
+    total = int(want["emit_len"].sum())
+    parts, emits, at = [], [], 0
+    for rank in range(world):
+        z = np.load(tmp_path / ("range%d.npz" % rank))
+        assert int(z["offset"]) == at and int(z["total"]) == total
+        parts.append(z["pcm"])
+        emits.append(z["emit"])
+        at += z["pcm"].shape[1]
+    assert np.array_equal(np.concatenate(emits), want["emit_len"])
+    got = np.concatenate(parts, axis=1)
+    assert got.shape[1] == total
+    assert np.array_equal(got.view(np.uint32), want["pcm"][0][:, :total].view(np.uint32))
+
+
+def test_stream_positions_match_the_oracle_layout():
+    from oracle.oracle_binding import OracleSynth
+    spec = fixture_like_spec(2)
+    b = _long_stream(spec)
+    want = OracleSynth(spec, 1).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    _, emit = sharding.stream_positions(spec, b["packets"])
+    assert np.array_equal(emit.astype(np.uint32), want["emit_len"])

@@ -1,0 +1,222 @@
+// tools/mem_pattern_bench.hip — what can HBM deliver for the ACCESS PATTERN of the fused synthesis kernel, with no arithmetic?
+// One wavefront per (stream, run, channel) walks R consecutive 4 KiB blocks of its own region (8 KiB apart: the other channel's
+// block lies between), reading each block once (one block ahead) and writing one 4 KiB block per step into its own output plane,
+// 16 waves per CU — exactly the fused kernel's geometry (64 streams x 32 runs x 2 channels = 4096 waves). Variants:
+//   width   8 or 16 bytes per lane per instruction (global_load/store_dwordx2 vs dwordx4)
+//   layout  "runs": the kernel's geometry;  "linear": the same bytes as one flat copy (wave w handles blocks w, w + W, ...)
+//   pace    0: as fast as memory allows;  N > 0: N dependent FMAs per lane between load and store (a wave then issues its next
+//           request only every ~N*4 cycles, as a computing wave does)
+//   hipcc --offload-arch=gfx950 -O3 -o tools/mem_pattern_bench tools/mem_pattern_bench.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr uint32_t BLK = 1024;  // floats per block (one channel of one long packet)
+
+template <int WIDTH, bool LINEAR, bool WRITE>
+__global__ void __launch_bounds__(512, 4) walk(const float* __restrict__ in, float* __restrict__ out, uint32_t streams, uint32_t runs, uint32_t R,
+                                                uint32_t ppk, uint64_t plane, int pace) {
+  const uint32_t wave = blockIdx.x * 8 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t nwaves = streams * runs * 2;
+  if (wave >= nwaves) return;
+  const uint32_t c = wave & 1u, r = (wave >> 1) % runs, s = (wave >> 1) / runs;
+  constexpr int V = WIDTH / 4;            // floats per lane per instruction
+  constexpr int NI = BLK / (64 * V);      // instructions per block
+  typedef float vec __attribute__((ext_vector_type(V)));
+  auto src_of = [&](uint32_t q) -> const vec* {
+    const size_t blk = LINEAR ? (size_t)wave + (size_t)q * nwaves : ((size_t)s * ppk + (size_t)r * R + q) * 2 + c;
+    return (const vec*)(in + blk * BLK) + lane;
+  };
+  auto dst_of = [&](uint32_t q) -> vec* {
+    const size_t off = LINEAR ? ((size_t)wave + (size_t)q * nwaves) * BLK : ((size_t)s * 2 + c) * plane + ((size_t)r * R + q) * BLK;
+    return (vec*)(out + off) + lane;
+  };
+  vec cur[NI], nxt[NI];
+  {
+    const vec* p = src_of(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) cur[i] = p[64 * i];
+  }
+  for (uint32_t q = 0; q < R; ++q) {
+    const vec* p = src_of(q + 1 < R ? q + 1 : q);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) nxt[i] = p[64 * i];
+    float acc = cur[0][0];
+    for (int k = 0; k < pace; ++k) acc = __builtin_fmaf(acc, 1.0001f, 0.5f);
+    if (WRITE) {
+      vec* d = dst_of(q);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        vec v = cur[i];
+        v[0] += acc * 1e-30f;
+        d[64 * i] = v;
+      }
+    } else if (acc == 1234.5f) {
+      out[wave] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) cur[i] = nxt[i];
+  }
+}
+
+// one wave per (stream, run), both channels, PK packets (PK x 8 KiB contiguous) per step, one step ahead; 8-byte accesses
+template <int PK>
+__global__ void __launch_bounds__(512) walk_wide(const float* __restrict__ in, float* __restrict__ out, uint32_t streams, uint32_t runs, uint32_t R,
+                                                 uint32_t ppk, uint64_t plane) {
+  const uint32_t wave = blockIdx.x * 8 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (wave >= streams * runs) return;
+  const uint32_t r = wave % runs, s = wave / runs;
+  constexpr int NI = PK * 16;
+  typedef float vec __attribute__((ext_vector_type(2)));
+  vec cur[NI], nxt[NI];
+  auto load = [&](uint32_t q, vec (&b)[NI]) {
+    const vec* p = (const vec*)(in + (((size_t)s * ppk + (size_t)r * R + (q < R ? q : R - PK)) * 2) * BLK) + lane;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) b[i] = p[64 * i];
+  };
+  load(0, cur);
+  for (uint32_t q = 0; q < R; q += PK) {
+    load(q + PK, nxt);
+#pragma unroll
+    for (int k = 0; k < PK; ++k)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        vec* d = (vec*)(out + ((size_t)s * 2 + c) * plane + ((size_t)r * R + q + k) * BLK) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[64 * i] = cur[k * 16 + c * 8 + i];
+      }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) cur[i] = nxt[i];
+  }
+}
+
+template <int PK>
+static void run_wide(const char* name, const float* in, float* out, uint32_t streams, uint32_t runs, uint32_t R, uint64_t plane) {
+  const uint32_t ppk = runs * R, nwaves = streams * runs;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CHECK(hipEventRecord(e0, 0));
+    walk_wide<PK><<<(nwaves + 7) / 8, 512>>>(in, out, streams, runs, R, ppk, plane);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep && ms < best) best = ms;
+  }
+  const double bytes = (double)nwaves * R * BLK * 4 * 4;
+  printf("%-44s: %.3f ms  %.2f TB/s (read + write)\n", name, best, bytes / best / 1e9);
+}
+
+// one wave per (stream, run): BOTH channels (8 KiB contiguous per step in, 2 x 4 KiB out), DEPTH steps ahead
+template <int WIDTH, int DEPTH>
+__global__ void __launch_bounds__(512) walk_pair(const float* __restrict__ in, float* __restrict__ out, uint32_t streams, uint32_t runs, uint32_t R,
+                                                 uint32_t ppk, uint64_t plane, uint32_t wpb) {
+  const uint32_t wave = blockIdx.x * wpb + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if ((threadIdx.x >> 6) >= wpb || wave >= streams * runs) return;
+  const uint32_t r = wave % runs, s = wave / runs;
+  constexpr int V = WIDTH / 4;
+  constexpr int NI = 2 * BLK / (64 * V);
+  typedef float vec __attribute__((ext_vector_type(V)));
+  vec buf[DEPTH + 1][NI];
+  auto load = [&](uint32_t q, vec (&b)[NI]) {
+    const vec* p = (const vec*)(in + (((size_t)s * ppk + (size_t)r * R + (q < R ? q : R - 1)) * 2) * BLK) + lane;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) b[i] = p[64 * i];
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(d, buf[d]);
+  for (uint32_t q = 0; q < R; q += DEPTH + 1) {
+#pragma unroll
+    for (int ph = 0; ph <= DEPTH; ++ph) {  // rotating buffers, fully unrolled so that every index is static
+      if (q + ph >= R) break;
+      load(q + ph + DEPTH, buf[(ph + DEPTH) % (DEPTH + 1)]);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        vec* d = (vec*)(out + ((size_t)s * 2 + c) * plane + ((size_t)r * R + q + ph) * BLK) + lane;
+#pragma unroll
+        for (int i = 0; i < NI / 2; ++i) d[64 * i] = buf[ph][c * (NI / 2) + i];
+      }
+    }
+  }
+}
+
+template <int WIDTH, int DEPTH>
+static void run_pair(const char* name, const float* in, float* out, uint32_t streams, uint32_t runs, uint32_t R, uint64_t plane, uint32_t wpb) {
+  const uint32_t ppk = runs * R, nwaves = streams * runs;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CHECK(hipEventRecord(e0, 0));
+    walk_pair<WIDTH, DEPTH><<<(nwaves + wpb - 1) / wpb, 512>>>(in, out, streams, runs, R, ppk, plane, wpb);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep && ms < best) best = ms;
+  }
+  const double bytes = (double)nwaves * R * BLK * 4 * 4;
+  printf("%-44s: %.3f ms  %.2f TB/s (read + write)\n", name, best, bytes / best / 1e9);
+}
+
+template <int WIDTH, bool LINEAR, bool WRITE>
+static void run(const char* name, const float* in, float* out, uint32_t streams, uint32_t runs, uint32_t R, uint64_t plane, int pace) {
+  const uint32_t ppk = runs * R, nwaves = streams * runs * 2;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CHECK(hipEventRecord(e0, 0));
+    walk<WIDTH, LINEAR, WRITE><<<(nwaves + 7) / 8, 512>>>(in, out, streams, runs, R, ppk, plane, pace);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep && ms < best) best = ms;
+  }
+  const double bytes = (double)nwaves * R * BLK * 4 * (WRITE ? 2 : 1);
+  printf("%-34s pace %4d: %.3f ms  %.2f TB/s (%s)\n", name, pace, best, bytes / best / 1e9, WRITE ? "read + write" : "read only");
+}
+
+int main() {
+  const uint32_t streams = 64, runs = 32, R = 32;
+  const uint64_t plane = (uint64_t)runs * R * BLK + 64;
+  const size_t n_in = (size_t)streams * runs * R * 2 * BLK, n_out = (size_t)streams * 2 * plane;
+  float *in, *out;
+  CHECK(hipMalloc((void**)&in, n_in * 4));
+  CHECK(hipMalloc((void**)&out, n_out * 4));
+  CHECK(hipMemset(in, 0, n_in * 4));
+  CHECK(hipMemset(out, 0, n_out * 4));
+  for (int pace : {0}) {
+    run<8, false, true>("runs,   8 B/lane", in, out, streams, runs, R, plane, pace);
+    run<16, false, true>("runs,   16 B/lane", in, out, streams, runs, R, plane, pace);
+    run<8, true, true>("linear, 8 B/lane", in, out, streams, runs, R, plane, pace);
+    run<16, true, true>("linear, 16 B/lane", in, out, streams, runs, R, plane, pace);
+  }
+  // both channels per wave; 2048 waves x 32 steps (8 waves/CU: 4 waves per 512-thread block slot... wpb = waves used per block)
+  run_pair<8, 1>("pair 8 B, depth 1, 2048 waves (8/CU)", in, out, streams, runs, R, plane, 8);
+  run_pair<16, 1>("pair 16 B, depth 1, 2048 waves (8/CU)", in, out, streams, runs, R, plane, 8);
+  run_pair<8, 2>("pair 8 B, depth 2, 2048 waves (8/CU)", in, out, streams, runs, R, plane, 8);
+  run_pair<16, 2>("pair 16 B, depth 2, 2048 waves (8/CU)", in, out, streams, runs, R, plane, 8);
+  // 4096 waves x 16 steps (16 waves/CU)
+  run_pair<8, 1>("pair 8 B, depth 1, 4096 waves (16/CU)", in, out, streams, 2 * runs, R / 2, plane, 8);
+  run_pair<16, 1>("pair 16 B, depth 1, 4096 waves (16/CU)", in, out, streams, 2 * runs, R / 2, plane, 8);
+  run_pair<8, 2>("pair 8 B, depth 2, 4096 waves (16/CU)", in, out, streams, 2 * runs, R / 2, plane, 8);
+  run_wide<1>("wide: 8 KiB per step, 2048 waves", in, out, streams, runs, R, plane);
+  run_wide<2>("wide: 16 KiB per step, 2048 waves", in, out, streams, runs, R, plane);
+  run_wide<4>("wide: 32 KiB per step, 2048 waves", in, out, streams, runs, R, plane);
+  run_wide<2>("wide: 16 KiB per step, 4096 waves", in, out, streams, 2 * runs, R / 2, plane);
+  run_wide<1>("wide: 8 KiB per step, 1024 waves", in, out, streams, runs / 2, R * 2, plane);
+  run_wide<4>("wide: 32 KiB per step, 1024 waves", in, out, streams, runs / 2, R * 2, plane);
+  // 3072 waves (12/CU)
+  run_pair<8, 1>("pair 8 B, depth 1, 3072 waves (12/CU)", in, out, streams, 48, 21, plane, 8);
+  return 0;
+}

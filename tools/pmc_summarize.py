@@ -33,4 +33,10 @@ lk = out["kernels"].get("vsyn_fused_kernel", {}).get("pmc_mean_per_launch", {})
 if "FETCH_SIZE" in lk and "WRITE_SIZE" in lk:
     # KiB units; FETCH_SIZE counts half of the streamed bytes on gfx950 (MI355X_MICROARCH.md HBM section; tools/fetch_calib.hip)
     out["long_kernel_hbm_bytes_per_launch"] = {"read_corrected": lk["FETCH_SIZE"] * 1024 * 2, "write": lk["WRITE_SIZE"] * 1024}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:  # the sources these counters were collected on: bench.py quotes the summary only while they are unchanged
+    from bench import csrc_fingerprint
+    out["csrc_fingerprint"] = csrc_fingerprint()
+except Exception as exc:
+    out["csrc_fingerprint_error"] = str(exc)[:200]
 print(json.dumps(out, indent=1, sort_keys=True))
