@@ -233,6 +233,8 @@ def main():
                          "e.g. --steps 3 --warmup 1 (one step = one pass over the rank's files)")
     ap.add_argument("--files-per-gpu", type=int, default=10640, help="config5: replicas of the stereo fixture per rank (94 audio packets each)")
     ap.add_argument("--host-threads", type=int, default=0, help="config5: entropy worker threads per rank (0: this rank's share of the cores, at most 16)")
+    ap.add_argument("--blocksizes", default="256,2048", help="config3/config4 with another blocksize pair, e.g. 128,1024 (diagnostic: the "
+                                                             "headline configurations are 256/2048)")
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--packets-per-stream", type=int, default=0)
     ap.add_argument("--vq-books", default="synthetic", choices=["synthetic", "fixture"],
@@ -278,7 +280,8 @@ def main():
 
     # rank 0 owns the stream setup; ONE broadcast of the (tiny) setup block splits the job, then ranks are independent
     from parseoggvorbis_amd import sharding
-    spec = fixture_like_spec(2 if args.workload != "config2" else 1) if rank == 0 else fixture_like_spec(1, 64, 64)
+    bs0, bs1 = (int(v) for v in args.blocksizes.split(","))
+    spec = fixture_like_spec(2 if args.workload != "config2" else 1, bs0, bs1) if rank == 0 else fixture_like_spec(1, 64, 64)
     spec = sharding.broadcast_spec(spec, device, src=0)
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -377,9 +380,9 @@ def main():
         bytes_per_unit = in_b + out_b
         if args.feature_taps:  # + the u16 curve of every bin
             bytes_per_unit += float(np.mean([spec.channels * (int(n) // 2) * 2 for n in b["n_of"]]))
-        wl = ("config3: %d stereo packets, blocksize 2048, %d streams x %d, floor+coupling+IMDCT+window+overlap-add"
-              % (b["P"], b["S"], ppk)) if pattern == "long" else \
-             ("config4: %d stereo packets, mixed 2048/256 (%.0f%% long), %d streams x %d" % (b["P"], 100 * lng_frac, b["S"], ppk))
+        wl = ("config3: %d stereo packets, blocksize %d, %d streams x %d, floor+coupling+IMDCT+window+overlap-add"
+              % (b["P"], spec.blocksize1, b["S"], ppk)) if pattern == "long" else \
+             ("config4: %d stereo packets, mixed %d/%d (%.0f%% long), %d streams x %d" % (b["P"], spec.blocksize1, spec.blocksize0, 100 * lng_frac, b["S"], ppk))
         if vq_entries_per_packet is not None:
             # the roofline object of this workload describes the residue VQ kernel: entry + classification numbers and
             # the two 16/32-byte descriptors in, the rebuilt residue out
@@ -549,7 +552,7 @@ def main():
         if traffic_detail is not None:
             traffic_detail["algorithmic_bytes_per_launch"] = round(bytes_per_unit * units)
         line = {
-            "metric": "audio packets/sec (blocksize 2048, stereo)" if args.workload == "config3" else "audio packets/sec",
+            "metric": "audio packets/sec (blocksize 2048, stereo)" if (args.workload == "config3" and spec.blocksize1 == 2048) else "audio packets/sec",
             "value": round(value, 1), "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

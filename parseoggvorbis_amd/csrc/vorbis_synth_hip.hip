@@ -21,6 +21,7 @@
 #include "vsyn_device.h"
 #include "vsyn_staged.h"
 #include "vsyn_fused.h"
+#include "vsyn_fused_u.h"
 #include "vsyn_vq.h"
 #include "vsyn_pcm.h"
 
@@ -106,8 +107,11 @@ struct vsyn_handle {
   float* d_carry = nullptr;
   DevStatus* d_status = nullptr;
   FusedTables fused{};
+  UTables utab{};
   bool fused_ok = false;
-  uint32_t fused_mask = 0;
+  uint32_t fused_mask = 0;             // what the layout kernel classifies by: bit 0 long-run kernel usable, bit 1 mixed-block runs fused too
+  uint32_t tuned_mask = 0;             // the same without the size-generic kernel (used when a tap it cannot write is requested)
+  bool u_mixed = false;                // class-2 runs go to the size-generic kernel (vsyn_fused_u.h) instead of fused_run<.., MIXED>
   int num_cus = 256;
   hipStream_t host_stream = nullptr;   // vsyn_submit_host: copies in, kernels, copies out
   hipStream_t side = nullptr;          // the (usually empty) staged work list runs beside the fused kernel
@@ -365,12 +369,25 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   }
   HC(h->ws_count.ensure(4));
   HC(hipMemset(h->ws_count.p, 0, sizeof(uint32_t) * 4));
-  h->fused_mask = fused_ok_mask(h->H, h->host_const.data());
-  h->fused_ok = h->fused_mask != 0;
+  h->fused_mask = h->tuned_mask = fused_ok_mask(h->H, h->host_const.data());
   if ((e = fused_tables_create(h->H, h->host_const.data(), &h->fused)) != hipSuccess) {
     fail(err, VSYN_ERR_HIP, "fused table upload failed: %s", hipGetErrorString(e));
     return cleanup(VSYN_ERR_HIP);
   }
+  // The size-generic kernel takes the mixed-block runs of every setup it covers: all of them where the 256/2048 kernel has no
+  // mixed path, and (VSYN_U_MIXED=1) in its place where it has one.
+  if (u_supported(h->H, h->host_const.data()) && !getenv("VSYN_NO_U")) {
+    const bool want = !(h->fused_mask & 2u) || (getenv("VSYN_U_MIXED") && atoi(getenv("VSYN_U_MIXED")));
+    if (want) {
+      if ((e = u_tables_create(h->H, h->host_const.data(), &h->utab)) != hipSuccess) {
+        fail(err, VSYN_ERR_HIP, "generic fused table upload failed: %s", hipGetErrorString(e));
+        return cleanup(VSYN_ERR_HIP);
+      }
+      h->u_mixed = true;
+      h->fused_mask |= 2u;
+    }
+  }
+  h->fused_ok = h->fused_mask != 0;
 #undef HC
   *out = h;
   return VSYN_OK;
@@ -404,6 +421,7 @@ void vsyn_destroy(vsyn_handle* h) {
   }
 #endif
   fused_tables_destroy(&h->fused);
+  u_tables_destroy(&h->utab);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->pre) (void)hipStreamDestroy(h->pre);
   if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
@@ -531,9 +549,14 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   // floor curve and the unwrapped posts — do not force them: the posts come from the unwrap kernel either way and
   // the curve from the tap variant of the fused kernel.
   const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct);
-  const bool force_staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !h->fused_ok;
+  // the size-generic kernel has no floor-curve tap: with that tap requested its runs go to the 256/2048 kernel's mixed path where
+  // that exists, to the staged kernels otherwise
+  const bool use_u = h->u_mixed && !(taps && taps->floor_curve);
+  const uint32_t fmask = use_u ? h->fused_mask : h->tuned_mask;
+  const bool force_staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !fmask;
   const uint32_t R = force_staged ? std::min<uint32_t>(max_seg_packets, 1024u)
-                                  : fused_pick_run_len(h->fused, S, C, max_seg_packets, h->num_cus);
+                                  : fused_pick_run_len((fmask & 1u) || !use_u ? h->fused.waves_per_cu : (int)h->utab.waves_per_cu, S, C,
+                                                       max_seg_packets, h->num_cus);
 
   // Workspace of this submit (double buffered). With VSYN_SUBMIT_INPUTS_READY the pre-kernels (layout scan, floor
   // unwrap: latency-bound, ~50 us) go to an internal stream and overlap the previous submit's synthesis kernel; they
@@ -572,7 +595,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
                         : (max_seg_packets > LAYOUT_LONG_PACKETS ? LAYOUT_THREADS_LONG : LAYOUT_THREADS);
     const uint32_t bitmap_packets = std::min<uint32_t>(max_seg_packets, LAYOUT_BITMAP_PACKETS);
     vsyn_layout_kernel<<<S, lt, layout_lds_bytes(lt, bitmap_packets), ps>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len,
-                                                                          h->d_status, R, force_staged ? 0u : h->fused_mask, list, cnt, cnt_next, segmap,
+                                                                          h->d_status, R, force_staged ? 0u : fmask, list, cnt, cnt_next, segmap,
                                                                           h->ws_runcls[wb].p, runs_per_seg, bitmap_packets);
   }
   {
@@ -596,7 +619,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   // fused kernel (disjoint outputs) and exit at once when the list is empty.
   // With the mixed-block kernel available every run is taken by one of the two fused kernels (run_class() never answers
   // 0 then; packets with an invalid mode are skipped by both paths): the staged kernels are not launched at all.
-  const bool staged_may_work = force_staged || !(h->fused_mask & 2u);
+  const bool staged_may_work = force_staged || !(fmask & 2u);
   hipStream_t ss = force_staged ? s : h->side;
   if (staged_may_work) {
     if (!force_staged) HIPCHK(hipStreamWaitEvent(h->side, h->ev_pre_done[wb], 0));
@@ -640,14 +663,27 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     a.plane_stride = plane_stride;
     a.S = S;
     a.R = R;
-    a.fused_ok = h->fused_mask;
+    a.fused_ok = use_u ? (fmask & 1u) : fmask;
     a.coupling_mode = (uint32_t)h->fused.coupling_mode;
     if (staged_may_work) HIPCHK(hipEventRecord(h->ev_join, h->side));
-    // one launch covers the long-run and the mixed-block runs (each wave takes the path of its run's class)
-    if (h->profile_which == 1 || h->profile_which == 2) HIPCHK(profile_begin(h, s, a.curve ? "vsyn_fused_tap_kernel" : fused_kernel_name(H)));
-    hipError_t e = fused_launch(H, h->fused, a, max_seg_packets, s);
-    if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
-    if (h->profile_which == 1 || h->profile_which == 2) HIPCHK(profile_end(h, s));
+    // one launch covers the long-run and the mixed-block runs of the 256/2048 kernel (each wave takes the path of its run's class);
+    // with the size-generic kernel in charge of the class-2 runs that is a second launch behind it (disjoint outputs)
+    const bool time_u = use_u && (h->profile_which == 2 || !(fmask & 1u));
+    hipError_t e = hipSuccess;
+    if (a.fused_ok) {
+      if (!time_u && (h->profile_which == 1 || h->profile_which == 2)) HIPCHK(profile_begin(h, s, a.curve ? "vsyn_fused_tap_kernel" : fused_kernel_name(H)));
+      e = fused_launch(H, h->fused, a, max_seg_packets, s);
+      if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "fused launch failed: %s", hipGetErrorString(e));
+      if (!time_u && (h->profile_which == 1 || h->profile_which == 2)) HIPCHK(profile_end(h, s));
+    }
+    if (use_u) {
+      FusedArgs au = a;
+      au.fused_ok = fmask;
+      if (time_u && (h->profile_which == 1 || h->profile_which == 2)) HIPCHK(profile_begin(h, s, "vsyn_fused_u_kernel"));
+      e = u_launch(H, h->utab, au, s);
+      if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "generic fused launch failed: %s", hipGetErrorString(e));
+      if (time_u && (h->profile_which == 1 || h->profile_which == 2)) HIPCHK(profile_end(h, s));
+    }
     if (staged_may_work) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   }
   HIPCHK(hipEventRecord(h->ev_main_done[wb], s));

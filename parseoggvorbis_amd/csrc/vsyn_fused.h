@@ -1015,10 +1015,10 @@ static inline const char* fused_kernel_name(const ConstHeader&) { return "vsyn_f
 static inline const char* fused_imdct_kernel_name(uint32_t) { return "vsyn_imdct_wave_kernel"; }
 
 // run length: as few runs as fill the chip once (halo overhead is 1/R), never below 4
-static inline uint32_t fused_pick_run_len(const FusedTables& ft, uint32_t S, uint32_t channels, uint32_t max_seg_packets, int num_cus) {
+static inline uint32_t fused_pick_run_len(int waves_per_cu, uint32_t S, uint32_t channels, uint32_t max_seg_packets, int num_cus) {
   const char* env = getenv("VSYN_RUN_LEN");
   if (env && atoi(env) > 0) return (uint32_t)atoi(env);
-  const uint64_t slots = (uint64_t)num_cus * (uint64_t)ft.waves_per_cu;
+  const uint64_t slots = (uint64_t)num_cus * (uint64_t)waves_per_cu;
   uint32_t R = 4;
   while (R < max_seg_packets && (uint64_t)S * channels * ((max_seg_packets + R - 1) / R) > slots) ++R;
   return R;

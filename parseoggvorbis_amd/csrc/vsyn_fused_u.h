@@ -1,0 +1,731 @@
+// vsyn_fused_u.h — the size-generic fused synthesis kernel ("U"): every block-size pair 64..2048 (the reference runs every
+// size through the same code, hpp:1294-1298, mdct.cpp:353-373), any mix of short and long blocks, carry-ins, <= 2 channels with
+// at most one coupling step, <= 64 floor posts. One wavefront per (segment, run, channel) as in vsyn_fused.h; what is new:
+//
+//   * a wave always works on 512 complex points = 8 per lane. A block of n samples has Np = n/4 points, so a PASS takes
+//     J = 512/Np consecutive packets of the same size and mapping at once (n = 256: 8 packets; n = 1024: 2; n = 2048: 1; at most 8):
+//     element (register t, lane l), e = 64 t + l, is point k = e mod Np of packet j = e div Np of the pass.
+//   * the FFT-Np of all J packets is the SAME three-pass network as the FFT-512 of vsyn_fused.h with the leading radix-2 stages
+//     of pass 1 (register index) resp. pass 2 switched off: DFT-R1 over the low register bits (R1 = Np/64), twiddle, exchange,
+//     DFT-8 (or 4 / 2 when Np < 64) over lane bits 5..3, twiddle, exchange, DFT-8 over lane bits 2..0. Afterwards packet j sits in
+//     the G = Np/8 consecutive lanes [jG, (j+1)G), bin f = kappa(lane) + G c' in register c'. All size dependence is in host-built
+//     lane-major tables (ULdsSize) and a few wave-uniform scalars: the device code is one instance.
+//   * the overlap term of packet j comes from packet j-1 of the same pass (G lanes below, one ds_bpermute per register), from the
+//     previous pass (registers), or — when the block size changes — through the wave's carry image, exactly as in vsyn_fused.h.
+//   * the floor curve is evaluated in bin order (4 consecutive bins per lane, tables per packet in turn) into the idle exchange
+//     image and read back in element order; everything else follows vsyn_fused.h (same roundings: coupling and floor product
+//     bit-exact, window product and overlap sum rounded separately, hpp:1008-1017).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vsyn_device.h"
+#include "vsyn_fused.h"
+
+struct ULdsSize {           // one block size; every table in exactly the order the lanes read it
+  float2 pre[8][64];        // element (t, lane): pre-rotation exp(-i pi (4k+1)/(4M)) of its point k
+  float2 post[8][64];       // (c', lane): post-rotation exp(-i pi f / M) of bin f
+  float2 tw1[8][64];        // pass-1 twiddle W_Np^(lane * t') (1 where the pass is absent)
+  float2 tw2[8][8];         // pass-2 twiddle [a][c]
+  float win[2][2][8][64];   // [window flag][0: at s, 1: at M-1-s][c'][lane]: left half of the window (hpp:850-859); the right half
+                            // for next-flag f is its mirror. Short blocks: both flags hold the one short window
+};
+struct ULdsImage {
+  ULdsSize sz[2];           // [0] blocksize0, [1] blocksize1
+  float invdb[260];         // Vorbis I 10.1; [255] = 1.0f, [256] = 0.0f as in FusedLdsImage
+};
+
+// per-wave LDS block (dynamic): exchange image | floor entries | packet info of the pass | hand-off flags | carry image
+#define U_XB_BYTES 4608u
+#define U_SEG_OFF U_XB_BYTES
+#define U_PINF_OFF (U_SEG_OFF + 512u)
+#define U_FLAG_OFF (U_PINF_OFF + 256u)
+#define U_CBUF_OFF (U_FLAG_OFF + 16u)
+#define U_MAX_J 8u
+#ifndef U_MAX_THREADS
+#define U_MAX_THREADS 768  // 12 waves per workgroup, one workgroup per CU: 168 VGPRs per wave
+#endif
+
+struct UArgs {
+  FusedArgs f;
+  const ULdsImage* img;
+  uint32_t wave_bytes;      // per-wave LDS block size (multiple of 16)
+  uint32_t table_bytes;     // sizeof(ULdsImage) rounded up
+};
+
+__device__ __forceinline__ void u_dft4(float2& x0, float2& x1, float2& x2, float2& x3) {  // natural order, forward
+  const float2 a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = mul_mi(csub(x1, x3));
+  x0 = cadd(a, c);
+  x1 = cadd(b, d);
+  x2 = csub(a, c);
+  x3 = csub(b, d);
+}
+// DFT of size 2^stages over the low `stages` bits of the register index, batched over the high bits (stages wave-uniform)
+__device__ __forceinline__ void u_dft_regs(float2 (&z)[8], uint32_t stages) {
+  if (stages == 3u) {
+    dft8(z);
+  } else if (stages == 2u) {
+    u_dft4(z[0], z[1], z[2], z[3]);
+    u_dft4(z[4], z[5], z[6], z[7]);
+  } else if (stages == 1u) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const float2 s = cadd(z[i], z[i + 1]), d = csub(z[i], z[i + 1]);
+      z[i] = s;
+      z[i + 1] = d;
+    }
+  }
+}
+
+typedef uint32_t u_u32x4 __attribute__((ext_vector_type(4)));
+typedef float u_f32x4 __attribute__((ext_vector_type(4)));
+typedef float u_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u_u32x4 u_lds_u32x4;
+typedef __attribute__((address_space(3))) u_f32x4 u_lds_f32x4;
+typedef __attribute__((address_space(3))) u_f32x2 u_lds_f32x2;
+
+// what a wave knows about one pass (all wave-uniform)
+struct UPass {
+  uint32_t q, Jp, LG, lng, map, last_widx, qn, buf;
+  bool valid, after_bad;  // after_bad: an invalid packet was skipped in front of this pass (the overlap chain restarts)
+};
+
+template <int ROLE>
+__device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, uint8_t* wmem, const uint8_t* pmem, const uint32_t lane, const uint32_t g,
+                                      const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c) {
+  const uint8_t* __restrict__ cb = A.cb;
+  const ConstHeader* H = hdr_of(cb);
+  float2* const xb = (float2*)wmem;
+  const float2* const pxb = (const float2*)pmem;
+  float* const stage = (float*)wmem;  // floor factors of the pass in bin order (the exchange image is idle between hand-off and FFT)
+  float2* const seg2 = (float2*)(wmem + U_SEG_OFF);
+  lds_u32* const pinf_base = (lds_u32*)(wmem + U_PINF_OFF);  // packet table of the pass in work
+  lds_u32* const my_flags = (lds_u32*)(wmem + U_FLAG_OFF);
+  const lds_u32* const partner_flags = (const lds_u32*)(pmem + U_FLAG_OFF);
+  lds_f32* const cbuf = (lds_f32*)(wmem + U_CBUF_OFF);
+
+  const uint32_t num = sg.num_packets;
+  const uint32_t lgp[2] = {__builtin_amdgcn_readfirstlane(H->lg[0]) - 2u, __builtin_amdgcn_readfirstlane(H->lg[1]) - 2u};  // log2(points)
+  const uint32_t ys_stride = __builtin_amdgcn_readfirstlane(H->ys_stride);
+  const uint32_t half1 = __builtin_amdgcn_readfirstlane(H->bs[1]) / 2u;
+  const MapConst* const maps = (const MapConst*)(cb + H->off_map);
+  const FloorConst* const floors = (const FloorConst*)(cb + H->off_floor);
+  const size_t carry_half = (size_t)H->max_streams * C * half1;
+  float* const plane = A.pcm + ((size_t)g * C + c) * A.plane_stride;
+  const PktInfo* const ip = A.info + sg.first_packet;
+
+  float P[8];  // unwindowed right-half values of the previous block, in the lanes of group 0 (see the carry step below)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) P[k] = 0.f;
+  uint32_t prev_M = 0;          // half size of the previous block, 0: none (0 * w + x == x: the arithmetic needs no special case)
+  uint32_t prev_kind = K_REG;
+  uint32_t prev_next_long = 1;
+  const float* cin = nullptr;
+  const uint32_t q0 = qa ? qa - 1u : 0u;
+  if (qa == 0 && si.has_carry) {
+    cin = A.carry + si.parity_in * carry_half + ((size_t)sg.stream * C + c) * half1;
+    prev_M = si.carry_n / 2u;
+    prev_kind = K_CARRY;
+  }
+  // floor in use (wave-uniform; reloaded when it changes)
+  int cur_floor = -1;
+  uint32_t cur_floor_M = 0, posts = 0, sidx = 0, xsl = 0;
+  uint32_t bsegw[4] = {0, 0, 0, 0};  // sorted-post interval of this lane's bins 4 lane + 256 i + {0..3}, one byte each
+
+  // packet descriptors of the candidates of the pass to be formed next: lane j < 8 holds packet (start) + j
+  u_u32x4 nfa = {0, 0, 0, 0}, nfb = {0, 0, 0, 0};
+  auto fetch_info = [&](uint32_t qq) {
+    const uint32_t idx = min(qq + (lane & 7u), qb - 1u);
+    const u_u32x4* p = (const u_u32x4*)(ip + idx);
+    nfa = p[0];
+    nfb = p[1];
+  };
+  // Form the pass that starts at packet qs from the descriptors in nfa/nfb (already landed): consecutive valid packets of one size
+  // and mapping, at most J; packet table into pinf[buf]; then request the descriptors behind it.
+  auto form = [&](uint32_t qs, uint32_t buf) -> UPass {
+    UPass ps;
+    ps.after_bad = false;
+    ps.valid = false;
+    ps.buf = buf;
+    while (qs < qb) {
+      const uint32_t bad0 = __builtin_amdgcn_readfirstlane((nfb[3] >> 8) & 0xFFu);
+      if (!bad0) break;
+      ps.after_bad = true;  // invalid mode number (flagged by the layout kernel): nothing to synthesise
+      ++qs;
+      if (qs < qb) {
+        fetch_info(qs);
+        vmem_drain();
+      }
+    }
+    ps.q = qs;
+    if (qs >= qb) {
+      ps.Jp = ps.LG = ps.lng = ps.map = ps.last_widx = 0;
+      ps.qn = qb;
+      return ps;
+    }
+    const bool cand = lane < U_MAX_J && qs + lane < qb;
+    const uint32_t bad_l = (nfb[3] >> 8) & 0xFFu, lng_l = (nfb[2] >> 16) & 0xFFu, map_l = nfb[3] & 0xFFu;
+    ps.lng = __builtin_amdgcn_readfirstlane(lng_l);
+    ps.map = __builtin_amdgcn_readfirstlane(map_l);
+    ps.LG = ps.lng ? lgp[1] : lgp[0];
+    const uint32_t J = min(U_MAX_J, 512u >> ps.LG);
+    const uint64_t okm = __ballot(cand && !bad_l && lng_l == ps.lng && map_l == ps.map && lane < J);
+    ps.Jp = (uint32_t)__builtin_ctzll(~okm);  // >= 1
+    // {res_off lo, hi, out_pos, emit (0 for the halo), used, own, widx, -}
+    if (lane < ps.Jp) {
+      lds_u32* pinf = pinf_base + 64u * buf;
+      u_u32x4 a = nfa;
+      if (qs + lane < qa) a[3] = 0u;
+      u_u32x4 b = {nfb[0], nfb[1], nfb[2] >> 24, 0u};
+      *(u_lds_u32x4*)(pinf + 8u * lane) = a;
+      *(u_lds_u32x4*)(pinf + 8u * lane + 4u) = b;
+    }
+    ps.qn = qs + ps.Jp;
+    ps.last_widx = __builtin_amdgcn_readlane(nfb[2] >> 24, ps.Jp - 1u);
+    if (ps.qn < qb) fetch_info(ps.qn);
+    ps.valid = true;
+    return ps;
+  };
+  float2 raw[8];
+  uint32_t vrow[U_MAX_J];
+  auto load_residue = [&](const UPass& ps) {
+    const lds_u32* pinf = pinf_base + 64u * ps.buf;
+    const uint32_t Mp = 2u << ps.LG, kmask = (1u << ps.LG) - 1u;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t e = 64u * t + lane, jt = e >> ps.LG, k = e & kmask;
+      const uint32_t jc = min(jt, ps.Jp - 1u);
+      typedef uint32_t u_u32x2 __attribute__((ext_vector_type(2)));
+      const u_u32x2 ro = *(const __attribute__((address_space(3))) u_u32x2*)(pinf + 8u * jc);
+      const uint64_t off = ((uint64_t)ro[1] << 32) | ro[0];
+      raw[t] = ((const float2*)(A.residue + off + (size_t)c * Mp))[k];
+    }
+  };
+  auto load_rows = [&](const UPass& ps) {
+    const uint32_t p0 = sg.first_packet + ps.q;
+#pragma unroll
+    for (uint32_t j = 0; j < U_MAX_J; ++j) {
+      const uint32_t pj = p0 + min(j, ps.Jp - 1u);
+      vrow[j] = (A.fy + ((size_t)pj * C + c) * ys_stride)[sidx];
+    }
+  };
+  auto floor_of_pass = [&](const UPass& ps) -> uint32_t { return __builtin_amdgcn_readfirstlane((uint32_t)maps[ps.map].chfloor[c]); };
+  auto floor_update = [&](uint32_t f, uint32_t Mp) {  // wave-uniform, rare
+    const FloorConst* fc = floors + f;
+    posts = __builtin_amdgcn_readfirstlane(fc->posts);
+    const uint8_t* bs = A.binseg + (size_t)f * half1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bsegw[i] = (4u * lane + 256u * i < Mp) ? *(const uint32_t*)(bs + 4u * lane + 256u * i) : 0u;
+    const bool in = lane < posts;
+    sidx = in ? fc->sorted_idx[lane] : 0u;
+    xsl = in ? fc->xs_sorted[lane] : 0u;
+    cur_floor = (int)f;
+    cur_floor_M = Mp;
+    vmem_drain();
+  };
+
+  fetch_info(q0);
+  vmem_drain();
+  uint32_t it = 0, qnext = q0;
+  for (;;) {
+    // (Forming the NEXT pass early and requesting its residue a pass ahead was measured: 24 more live registers, no gain at the 8-12
+    // waves per CU this kernel runs at — 0.221 vs 0.218 ms per 65 536 n = 1024 packets without spills, slower with them.)
+    const UPass cur = form(qnext, 0u);
+    if (!cur.valid) break;
+    if (cur.after_bad) {  // the chain restarts behind an invalid packet
+#pragma unroll
+      for (int k = 0; k < 8; ++k) P[k] = 0.f;
+      prev_M = 0;
+      prev_kind = K_REG;
+    }
+    if ((int)floor_of_pass(cur) != cur_floor || (2u << cur.LG) != cur_floor_M) floor_update(floor_of_pass(cur), 2u << cur.LG);
+    load_residue(cur);
+    load_rows(cur);
+    ++it;
+    const uint32_t LG = cur.LG, lng0 = cur.lng, Jp = cur.Jp, qn = cur.qn;
+    const uint32_t Np = 1u << LG, M = 2u * Np, G = Np >> 3, lgG = LG - 3u, kmask = Np - 1u;
+    const uint32_t p0 = sg.first_packet + cur.q;
+    const lds_u32* const pinf = pinf_base + 64u * cur.buf;
+
+    // ---- inverse coupling through the partner's image (hpp:1213-1241), as in vsyn_fused.h ------------------------------------------
+    float2 r[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (((64u * t + lane) >> LG) >= Jp) raw[t] = f2(0.f, 0.f);  // elements beyond the pass's last packet
+    if (ROLE != 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
+      pair_post(&my_flags[0], it);
+      pair_wait(&partner_flags[0], it);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float2 oth = pxb[t * 64 + lane];
+        r[t] = ROLE == 1 ? f2(couple_mag(raw[t].x, oth.x), couple_mag(raw[t].y, oth.y)) : f2(couple_ang(oth.x, raw[t].x), couple_ang(oth.y, raw[t].y));
+      }
+      pair_post(&my_flags[1], it);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) r[t] = raw[t];
+    }
+    // coded rows of this pass, two per register (the row registers are about to be reused)
+    uint32_t vcur[U_MAX_J / 2];
+#pragma unroll
+    for (uint32_t j = 0; j < U_MAX_J / 2; ++j) vcur[j] = (vrow[2 * j] & 0xFFFFu) | (vrow[2 * j + 1] << 16);
+
+    if (ROLE != 0) pair_wait(&partner_flags[1], it);  // the partner has read this wave's image: it may be reused (floor factors, FFT)
+
+    // ---- floor curve, packet by packet, in bin order (hpp:563-589) -----------------------------------------------------------------
+    bool floor_bad = false;
+    uint32_t floor_bad_pkt = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < U_MAX_J; ++j) {
+      if (j >= Jp) break;
+      const uint32_t own_j = pinf[8u * j + 5u], used_j = pinf[8u * j + 4u];
+      if (!((own_j >> c) & 1u)) {
+        seg2[lane] = f2(0.f, ((used_j >> c) & 1u) ? 256.5f : 255.5f);  // x1.0 resp. x0.0 (hpp:1159,1176-1179), as in vsyn_fused.h
+      } else {
+        uint32_t v = (vcur[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+        if (lane >= posts) v = 0;
+        const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
+        const uint64_t below = mask & ((2ull << lane) - 1ull);
+        const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
+        const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
+        const bool has_hi = above != 0ull;
+        const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
+        const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
+        const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
+        const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
+        if ((v & 0x7FFFu) > 255u) {
+          floor_bad = true;
+          floor_bad_pkt = p0 + j;
+        }
+        const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
+        const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
+        const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
+        const float ady = fabsf(y1 - y0);
+        const float a = ady * inv, b = __builtin_fmaf(-ady, x0, 0.5f) * inv;
+        seg2[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);  // index = floor(x a + b), see vsyn_fused.h
+      }
+      const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2;
+      const bool nocurve = !((own_j >> c) & 1u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (256u * i >= M) break;
+        if (4u * lane + 256u * i < M) {
+          const uint32_t w = nocurve ? 0u : bsegw[i];
+          u_f32x2 en[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) en[e] = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * ((w >> (8 * e)) & 0xFFu));
+          u_f32x4 fl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t ix = (uint32_t)__builtin_fmaf((float)(4u * lane + 256u * i + e), en[e].x, en[e].y);
+            fl[e] = T.invdb[ix];
+          }
+          *(u_lds_f32x4*)(lds_f32*)(stage + j * M + 4u * lane + 256u * i) = fl;
+        }
+      }
+    }
+    // floor product in element order (hpp:1243-1255)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t e = 64u * t + lane, jt = min(e >> LG, Jp - 1u), k = e & kmask;
+      const u_f32x2 f = *(const u_lds_f32x2*)(lds_f32*)(stage + jt * M + 2u * k);
+      r[t] = f2(r[t].x * f.x, r[t].y * f.y);
+    }
+
+    // ---- IMDCT: mirror element, pre-rotation, FFT-Np x J, post-rotation (mdct.cpp:433-527 by the DCT-IV route) ---------------------
+    const ULdsSize& TS = T.sz[lng0 ? 1 : 0];
+    float2 z[8];
+    {
+      const int ml = (int)(lane ^ min(63u, kmask));  // lane of the mirror point Np-1-k; its register is t ^ ((Np-1) >> 6)
+      float im[8];
+      const uint32_t tm = kmask >> 6;
+      if (tm == 7u) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) im[t] = __shfl(r[7 - t].y, ml);
+      } else if (tm == 3u) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) im[t] = __shfl(r[t ^ 3].y, ml);
+      } else if (tm == 1u) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) im[t] = __shfl(r[t ^ 1].y, ml);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) im[t] = __shfl(r[t].y, ml);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) z[t] = cmulf(f2(r[t].x, im[t]), TS.pre[t][lane]);
+    }
+    {
+      const uint32_t cl = lane & 7u, hi = lane >> 3;
+      const uint32_t p1 = LG > 6u ? LG - 6u : 0u, p2 = LG >= 6u ? 3u : LG - 3u;
+      if (p1) {
+        u_dft_regs(z, p1);
+#pragma unroll
+        for (int t = 1; t < 8; ++t) z[t] = cmulf(z[t], TS.tw1[t][lane]);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xb[t * 72 + lane] = z[t];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) z[a] = xb[hi * 72 + a * 8 + cl];
+      u_dft_regs(z, p2);
+#pragma unroll
+      for (int a = 1; a < 8; ++a) z[a] = cmulf(z[a], TS.tw2[a][cl]);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) xb[a * 65 + lane] = z[a];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = xb[cl * 65 + hi * 8 + k];
+      dft8(z);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], TS.post[k][lane]);
+
+    // ---- window + overlap-add + PCM (hpp:1008-1059) --------------------------------------------------------------------------------
+    // bin f = kappa + G c' of packet jo = lane >> lgG; left-half samples s = 2f - Np (c' >= 4) resp. Np - 1 - 2f, and M-1-s
+    const uint32_t jo = lane >> lgG, gl = lane & (G - 1u);
+    const uint32_t kappa = LG >= 6u ? (((lane >> 3) & ((1u << (LG - 6u)) - 1u)) | ((lane & 7u) << (LG - 6u))) : gl;
+    const bool valid_o = jo < Jp;
+    const uint32_t jq = min(jo, Jp - 1u);
+    const u_u32x4 oi = *(const u_lds_u32x4*)(pinf + 8u * jq);
+    const uint32_t widx_o = pinf[8u * jq + 6u];
+    const uint32_t emit = valid_o ? oi[3] : 0u;
+    float* const out = plane + oi[2];
+    const bool grp0 = jo == 0u;
+    // chunk of a packet = [centre of the previous block, centre of this one): left-half sample s sits at frame s + shift
+    const uint32_t shift = (grp0 && prev_M && prev_M != M) ? (uint32_t)(((int32_t)prev_M - (int32_t)M) / 2) : 0u;  // negative (wrapped) after a smaller block
+    const uint32_t fL = lng0 ? (widx_o & 1u) : 0u;
+    uint32_t fR = lng0 ? prev_next_long : 0u;
+    if (lng0 && !grp0) fR = (pinf[8u * (jq ? jq - 1u : 0u) + 6u] >> 1) & 1u;
+    float wl0[8], wl1[8], wr0[8], wr1[8], Pin[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wl0[k] = TS.win[fL][0][k][lane];
+      wl1[k] = TS.win[fL][1][k][lane];
+    }
+    if (__all(fL == fR)) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        wr0[k] = wl0[k];
+        wr1[k] = wl1[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        wr0[k] = TS.win[fR][0][k][lane];
+        wr1[k] = TS.win[fR][1][k][lane];
+      }
+    }
+    // this pass's own right-half values (unwindowed), then the overlap term of every packet: from the packet G lanes below, or
+    // (first packet of the pass) from the previous pass
+    float Pn[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Pn[k] = k >= 4 ? z[k].y : -z[k].x;
+    if (G < 64u) {
+      const int below = (int)((lane - G) & 63u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float sh = __shfl(Pn[k], below);
+        Pin[k] = grp0 ? P[k] : sh;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Pin[k] = P[k];
+    }
+    if (prev_kind == K_CARRY && prev_M != M) {
+      // carry-in of another block size (wave-uniform, first pass only): into the carry image, as a block of this submit would have
+      // left it; a larger block also owns the first D frames of the chunk outright
+      if (prev_M > M) {
+        const uint32_t D = (prev_M - M) / 2u;
+        const uint32_t e0 = __builtin_amdgcn_readfirstlane(pinf[3]), o0 = __builtin_amdgcn_readfirstlane(pinf[2]);  // the pass's first packet
+        for (uint32_t i = lane; i < min(D, e0); i += 64) plane[o0 + i] = cin[i];
+        for (uint32_t i = lane; i < M; i += 64) cbuf[i] = cin[D + i];
+      } else {
+        for (uint32_t i = lane; i < prev_M; i += 64) cbuf[i] = cin[i];
+      }
+      prev_kind = K_LDS;
+    }
+    if (prev_kind != K_REG && grp0) {
+      // the overlap term arrives already windowed (carry-in of an earlier submit, or the previous block had another size):
+      // as P = 1 and "window" = the value itself (1 * x == x), so that the arithmetic below stays one straight line
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t f = kappa + G * k;
+        const uint32_t s = k >= 4 ? 2u * f - Np : Np - 1u - 2u * f;
+        float vs, vm;
+        if (prev_kind == K_CARRY) {  // same size: natural order
+          vs = cin[s];
+          vm = cin[M - 1u - s];
+        } else if (prev_M < M) {  // after a smaller block: its prev_M windowed samples meet this block's samples [D, D + prev_M)
+          const uint32_t D = (M - prev_M) / 2u;
+          const bool in = s >= D && s < D + prev_M;
+          vs = in ? cbuf[s - D] : 0.f;
+          vm = in ? cbuf[M - 1u - s - D] : 0.f;
+        } else {  // after a larger block: the image holds the M frames of its right half that overlap this block
+          vs = cbuf[s];
+          vm = cbuf[M - 1u - s];
+        }
+        Pin[k] = 1.f;
+        wr1[k] = vs;
+        wr0[k] = vm;
+      }
+    }
+    // Everything in flight here is loads (the next pass's residue, rows and descriptors; carry-in reads): finish them before the PCM
+    // stores go out, so that nothing later in the loop ever waits for a store (see vmem_drain)
+    vmem_drain();
+    const bool last_of_segment = qn == num;
+    uint32_t next_M = 0, next_emit = 0, next_out = 0;
+    if (qn < qb) {  // nfa/nfb hold the descriptors behind this pass by now
+      const uint32_t nbad = __builtin_amdgcn_readfirstlane((nfb[3] >> 8) & 0xFFu), nlng = __builtin_amdgcn_readfirstlane((nfb[2] >> 16) & 0xFFu);
+      next_M = nbad ? 0u : (2u << (nlng ? lgp[1] : lgp[0]));
+      next_emit = __builtin_amdgcn_readfirstlane(qn < qa ? 0u : nfa[3]);
+      next_out = __builtin_amdgcn_readfirstlane(nfa[2]);
+    }
+    const bool hand_over = next_M && next_M != M;
+    float oh_s[4], oh_m[4], n_s[4], n_m[4];
+    const int mirror = (int)(lane ^ (G - 1u));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kh = 4 + j, kl = 3 - j;
+      const float cch = z[kh].x, ccl = -z[kl].y;
+      const float ah_s = Pin[kh] * wr1[kh], ah_m = Pin[kh] * wr0[kh], al_s = Pin[kl] * wr1[kl], al_m = Pin[kl] * wr0[kl];
+      oh_s[j] = ah_s + cch * wl0[kh];
+      oh_m[j] = ah_m + (-cch) * wl1[kh];
+      const float ol_s = al_s + ccl * wl0[kl];
+      const float ol_m = al_m + (-ccl) * wl1[kl];
+      n_s[j] = __shfl(ol_s, mirror);  // bin Np-1-f (mirror lane of the group, register 7-c') yields the neighbouring samples
+      n_m[j] = __shfl(ol_m, mirror);
+    }
+    {
+      // sample s = 2 kappa + 2 G j of (lane, c' = 4 + j): s, s+1 and M-2-s, M-1-s
+      const bool whole = emit == M + shift && (int)shift >= 0 && (((uintptr_t)out & 7u) == 0);  // every left-half sample is inside the chunk
+      if (__all(whole || !valid_o)) {
+        if (valid_o) {
+          float* up = out + shift + 2u * kappa;
+          float* dn = out + shift + M - 2u - 2u * kappa;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            *(float2*)(up + 2u * G * j) = f2(oh_s[j], n_s[j]);
+            *(float2*)(dn - 2u * G * j) = f2(n_m[j], oh_m[j]);
+          }
+        }
+      } else if (emit) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t s = 2u * kappa + 2u * G * j;
+          const uint32_t f0 = s + shift, f1 = s + 1u + shift, f2m = M - 2u - s + shift, f3m = M - 1u - s + shift;
+          if (f0 < emit) out[f0] = oh_s[j];
+          if (f1 < emit) out[f1] = n_s[j];
+          if (f2m < emit) out[f2m] = n_m[j];
+          if (f3m < emit) out[f3m] = oh_m[j];
+        }
+      }
+    }
+
+    // ---- what the last packet of the pass leaves behind -----------------------------------------------------------------------------
+    const uint32_t cur_next_long = lng0 ? (cur.last_widx >> 1) & 1u : 0u;
+    if ((last_of_segment || hand_over) && jo == Jp - 1u) {
+      // windowed right half in natural order: sample s of bin f at position s. Segment end: all of it into the stream's carry buffer.
+      // Before a smaller block: frames [0, D) are final and go straight into the next chunk, [D, D + next_M) into the carry image,
+      // the rest is windowed to zero. Before a larger block: all M frames into the carry image.
+      float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * half1;
+      float* nxtp = plane + next_out;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t f = kappa + G * k;
+        const uint32_t s = k >= 4 ? 2u * f - Np : Np - 1u - 2u * f, sm = M - 1u - s;
+        const float v_s = Pn[k] * TS.win[cur_next_long][1][k][lane], v_m = Pn[k] * TS.win[cur_next_long][0][k][lane];
+        if (last_of_segment) {
+          cout[s] = v_s;
+          cout[sm] = v_m;
+        } else if (next_M < M) {
+          const uint32_t D = (M - next_M) / 2u;
+          if (s < D) {
+            if (s < next_emit) nxtp[s] = v_s;
+          } else if (s < D + next_M) {
+            cbuf[s - D] = v_s;
+          }
+          if (sm < D) {
+            if (sm < next_emit) nxtp[sm] = v_m;
+          } else if (sm < D + next_M) {
+            cbuf[sm - D] = v_m;
+          }
+        } else {
+          cbuf[s] = v_s;
+          cbuf[sm] = v_m;
+        }
+      }
+    }
+    // carry registers for the next pass: the last packet's values, moved to the lanes of group 0
+    if (G < 64u) {
+      const int from = (int)((Jp - 1u) * G + gl);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) P[k] = __shfl(Pn[k], from);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) P[k] = Pn[k];
+    }
+    if (__any(floor_bad)) {
+      if (floor_bad) raise_status(A.status, VSYN_ST_FLOOR_VALUE, floor_bad_pkt);
+      vmem_drain();
+    }
+    prev_kind = hand_over ? K_LDS : K_REG;
+    prev_M = M;
+    prev_next_long = cur_next_long;
+    qnext = qn;
+    if (qnext >= qb) break;
+  }
+}
+
+// grid: groups of WPB = blockDim.x / 64 units (segment, run, channel), flattened as in vsyn_fused_kernel; the channels of a run are
+// adjacent waves of one workgroup. Takes every run of class 2 (with the tuned long-run kernel absent: every run).
+__global__ void __launch_bounds__(U_MAX_THREADS) vsyn_fused_u_kernel(const UArgs U) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t u_lds[];
+  const FusedArgs& A = U.f;
+  const ConstHeader* H = hdr_of(A.cb);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t WPB = blockDim.x >> 6;
+  const uint32_t C = H->channels;
+  const uint32_t per_seg = A.runs_per_seg * C;
+  const uint32_t unit = blockIdx.x * WPB + wave;
+  const uint32_t g = __builtin_amdgcn_readfirstlane(unit / per_seg);
+  const uint32_t rem = unit - g * per_seg;
+  const uint32_t run = __builtin_amdgcn_readfirstlane(rem / C), c = __builtin_amdgcn_readfirstlane(rem % C);
+  vsyn_segment sg = {};
+  SegInfo si = {};
+  uint32_t cls = 0xFFu;
+  if (g < A.S) {
+    sg = A.segs[g];
+    if (sg.stream < H->max_streams && !(sg.residue_off & 3)) {
+      si = A.sinfo[g];
+      cls = __builtin_amdgcn_readfirstlane((uint32_t)A.run_cls[(size_t)g * A.runs_per_seg + run]);
+    }
+  }
+  const uint32_t qa = run * A.R;
+  const uint32_t qb = min(sg.num_packets, qa + A.R);
+  const bool active = cls == 2u && (A.fused_ok & 2u);
+  if (!__syncthreads_or(active ? 1 : 0)) return;
+  {
+    const uint4* src = (const uint4*)U.img;
+    uint4* dst = (uint4*)u_lds;
+    for (uint32_t i = threadIdx.x; i < sizeof(ULdsImage) / 16; i += blockDim.x) dst[i] = src[i];
+  }
+  uint8_t* wmem = u_lds + U.table_bytes + wave * U.wave_bytes;
+  if (lane < 2) ((uint32_t*)(wmem + U_FLAG_OFF))[lane] = 0u;
+  __syncthreads();
+  if (!active) return;
+  const ULdsImage& T = *(const ULdsImage*)u_lds;
+  const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u;
+  const int role = (A.coupling_mode == 0 || C < 2) ? 0 : (c == mag ? 1 : 2);
+  const uint32_t pw = role ? (wave ^ 1u) : wave;
+  const uint8_t* pmem = u_lds + U.table_bytes + pw * U.wave_bytes;
+  if (role == 0) u_run<0>(A, T, wmem, pmem, lane, g, sg, si, qa, qb, C, c);
+  else if (role == 1) u_run<1>(A, T, wmem, pmem, lane, g, sg, si, qa, qb, C, c);
+  else u_run<2>(A, T, wmem, pmem, lane, g, sg, si, qa, qb, C, c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct UTables {
+  ULdsImage* d_img = nullptr;
+  uint32_t wave_bytes = 0, table_bytes = 0, waves_per_block = 0, waves_per_cu = 0;
+};
+
+static inline bool u_supported(const ConstHeader& H, const uint8_t* host_const) {
+  if (H.bs[1] > 2048 || H.channels > 2) return false;
+  const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
+  for (uint32_t f = 0; f < H.num_floors; ++f)
+    if (fl[f].posts > 64) return false;
+  // one coupling structure for every mapping (the role of a wave is fixed for the launch)
+  const MapConst* mp = (const MapConst*)(host_const + H.off_map);
+  int want = -2;
+  for (uint32_t k = 0; k < H.num_modes; ++k) {
+    const MapConst& m = mp[H.mode_mapping[k]];
+    const int cur = m.ncoup == 0 ? 0 : (m.ncoup == 1 ? (m.coup[0] == 0 ? 1 : 2) : -1);
+    if (cur < 0) return false;
+    if (want == -2) want = cur;
+    else if (want != cur) return false;
+  }
+  return true;
+}
+
+static inline void u_fill_size(const ConstHeader& H, const uint8_t* host_const, int b, ULdsSize& S) {
+  const uint32_t n = H.bs[b], M = n / 2, Np = n / 4;
+  uint32_t LG = 0;
+  while ((1u << LG) < Np) ++LG;
+  const uint32_t p1 = LG > 6 ? LG - 6 : 0, R1 = 1u << p1, G = Np / 8;
+  const float2* pre = (const float2*)(host_const + H.off_pre[b]);
+  const float2* post = (const float2*)(host_const + H.off_post[b]);
+  const float2* tw = (const float2*)(host_const + H.off_fft[b]);  // W_Np^j
+  const float* win = (const float*)(host_const + H.off_win[b]);
+  for (uint32_t l = 0; l < 64; ++l) {
+    const uint32_t gl = l & (G - 1), kappa = LG >= 6 ? (((l >> 3) & (R1 - 1)) | ((l & 7) << p1)) : gl;
+    for (uint32_t t = 0; t < 8; ++t) {
+      const uint32_t e = 64 * t + l, k = e & (Np - 1);
+      S.pre[t][l] = pre[k];
+      const uint32_t tl = t & (R1 - 1);
+      S.tw1[t][l] = LG >= 6 ? tw[(l * tl) & (Np - 1)] : make_float2(1.f, 0.f);
+      const uint32_t f = kappa + G * t;  // t plays c' here
+      S.post[t][l] = post[f & (Np - 1)];
+      const uint32_t s = t >= 4 ? 2 * f - Np : Np - 1 - 2 * f;
+      for (uint32_t fl = 0; fl < 2; ++fl) {
+        const uint32_t widx = b ? fl : 0;  // long: left half depends on the prev flag only (widx = prev + 2 next); short: one window
+        S.win[fl][0][t][l] = win[(size_t)widx * n + (s & (M - 1))];
+        S.win[fl][1][t][l] = win[(size_t)widx * n + ((M - 1 - s) & (M - 1))];
+      }
+    }
+  }
+  for (uint32_t a = 0; a < 8; ++a)
+    for (uint32_t c = 0; c < 8; ++c) {
+      if (LG >= 6) {
+        S.tw2[a][c] = tw[(c * a * (Np / 64)) & (Np - 1)];
+      } else {
+        const uint32_t R2 = Np / 8;
+        S.tw2[a][c] = tw[(c * (a & (R2 - 1))) & (Np - 1)];
+      }
+    }
+}
+
+static inline hipError_t u_tables_create(const ConstHeader& H, const uint8_t* host_const, UTables* ut) {
+  std::vector<ULdsImage> v(1);
+  memset(&v[0], 0, sizeof(ULdsImage));
+  u_fill_size(H, host_const, 0, v[0].sz[0]);
+  u_fill_size(H, host_const, 1, v[0].sz[1]);
+  memcpy(v[0].invdb, host_const + H.off_invdb, 256 * sizeof(float));
+  hipError_t e = hipMalloc((void**)&ut->d_img, sizeof(ULdsImage));
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(ut->d_img, &v[0], sizeof(ULdsImage), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return e;
+  ut->table_bytes = (uint32_t)((sizeof(ULdsImage) + 15u) & ~15u);
+  const uint32_t cbuf = H.bs[0] != H.bs[1] ? (H.bs[0] / 2) * 4u : 16u;
+  ut->wave_bytes = (U_CBUF_OFF + cbuf + 15u) & ~15u;
+  const uint32_t budget = 156u * 1024u;
+  uint32_t w = (budget - ut->table_bytes) / ut->wave_bytes;
+  w = std::min<uint32_t>(U_MAX_THREADS / 64u, w) & ~1u;
+  ut->waves_per_block = std::max<uint32_t>(2u, w);
+  ut->waves_per_cu = ut->waves_per_block;  // one workgroup per CU (the tables take a quarter of the LDS)
+  e = hipFuncSetAttribute((const void*)vsyn_fused_u_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(ut->table_bytes + ut->waves_per_block * ut->wave_bytes));
+  if (e != hipSuccess && getenv("VSYN_DEBUG"))
+    fprintf(stderr, "vsyn: hipFuncSetAttribute(%u B dynamic LDS) failed: %s\n", ut->table_bytes + ut->waves_per_block * ut->wave_bytes, hipGetErrorString(e));
+  return e;
+}
+
+static inline void u_tables_destroy(UTables* ut) {
+  if (ut->d_img) (void)hipFree(ut->d_img);
+  ut->d_img = nullptr;
+}
+
+static inline hipError_t u_launch(const ConstHeader& H, const UTables& ut, const FusedArgs& a, hipStream_t s) {
+  const uint64_t units = (uint64_t)a.S * a.runs_per_seg * H.channels;
+  if (units == 0 || units > 0x7FFFFFF0ull) return hipErrorInvalidValue;
+  UArgs u;
+  u.f = a;
+  u.img = ut.d_img;
+  u.wave_bytes = ut.wave_bytes;
+  u.table_bytes = ut.table_bytes;
+  const uint32_t wpb = ut.waves_per_block;
+  dim3 grid((uint32_t)((units + wpb - 1) / wpb));
+  vsyn_fused_u_kernel<<<grid, wpb * 64, ut.table_bytes + wpb * ut.wave_bytes, s>>>(u);
+  return hipGetLastError();
+}

@@ -82,6 +82,16 @@ SHAPES = [  # (channels, bs0, bs1, pattern, streams, packets)
     (3, 128, 1024, "mixed", 3, 21),
     (2, 512, 512, "short", 2, 8),
     (2, 2048, 4096, "mixed", 2, 12),
+    (2, 128, 1024, "mixed", 3, 40),    # the size-generic fused kernel: 2 long blocks / 8 short blocks per pass
+    (1, 128, 1024, "mixed", 2, 33),
+    (2, 512, 1024, "mixed", 2, 30),
+    (2, 1024, 1024, "long", 2, 20),
+    (2, 256, 256, "short", 3, 50),
+    (2, 64, 256, "mixed", 2, 61),
+    (1, 64, 128, "mixed", 2, 47),
+    (2, 2048, 2048, "long", 2, 12),
+    (2, 128, 2048, "mixed", 2, 45),
+    (2, 1024, 2048, "mixed", 2, 25),
     (2, 256, 2048, "mixed", 2, 2300),  # segments of several thousand packets: the layout kernel's bursts
     (1, 256, 2048, "mixed", 1, 16500),  # one very long segment: the layout kernel's 1024-thread block
 ]
