@@ -598,7 +598,13 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
                                                                           h->d_status, R, force_staged ? 0u : fmask, list, cnt, cnt_next, segmap,
                                                                           h->ws_runcls[wb].p, runs_per_seg, bitmap_packets);
   }
-  {
+  // Floor unwrap: a kernel of its own. The consuming waves can do it themselves (wave_unwrap in vsyn_fused.h, VSYN_UNWRAP_IN_WAVE=1,
+  // only when every run of the batch is taken by a fused kernel) — measured on config 3: the 4096 waves then all spend their first
+  // ~12 us in the serial post chain with the memory pipe idle (kernel 0.251 -> 0.263 ms, step 0.270 -> 0.281 ms), which costs more
+  // than the separate kernel's interference with the exact-fit grid; kept for batches too small to fill the chip.
+  const bool staged_may_work_pre = force_staged || !(fmask & 2u);
+  const bool unwrap_in_wave = !staged_may_work_pre && getenv("VSYN_UNWRAP_IN_WAVE") && atoi(getenv("VSYN_UNWRAP_IN_WAVE"));
+  if (!unwrap_in_wave) {
     const uint32_t rows = P * C;
     vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,
                                                                                                        d_ys, fy, h->d_status);
@@ -657,6 +663,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     a.residue = d_residue;
     a.curve = taps ? taps->floor_curve : nullptr;
     a.fy = fy;
+    a.ys = unwrap_in_wave ? d_ys : nullptr;
     a.pcm = d_pcm;
     a.carry = h->d_carry;
     a.status = h->d_status;

@@ -223,6 +223,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
     vmem_drain();
   };
 
+  if (A.ys) wave_unwrap(A, xb, lane, sg, q0, qb, C, c);
   fetch_info(q0);
   vmem_drain();
   uint32_t it = 0, qnext = q0;
