@@ -68,6 +68,9 @@ struct FusedLdsImage {
   float2 post_s[64];      // post-rotation of bin m = bitrev6(lane)
   float2 tws[6][64];      // DIF stage twiddles: stage i pairs lane l with l ^ (32 >> i); W_(64>>i)^(l & ((32>>i)-1))
   float wsl[2][64];       // short window at sample s(lane) and at 127 - s(lane)
+  // packed short pass (8 blocks of n = 256 at once, fused_short_pass): bin f = a' + 8 c' in register c' of the lanes with lane & 7 == a'
+  float2 post8[8][8];     // [c'][a'] post-rotation of bin f
+  float wsl8[2][8][8];    // [0: at s, 1: at 127 - s][c'][a'], s = 2f - 64 (c' >= 4) resp. 63 - 2f
 };
 
 struct FusedTables {
@@ -399,6 +402,263 @@ __device__ __forceinline__ void wave_unwrap(const FusedArgs& A, float2* xb_mem, 
   vmem_drain();  // the rows are read back by this wave: its stores have reached L2
 }
 
+enum { K_REG = 0, K_LDS = 1, K_CARRY = 2 };
+__device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
+
+// Packed short pass of the mixed-block path (blocksize0 = 256): up to 8 consecutive short blocks of one mapping at once. A short
+// block has 64 complex points, so element (register t, lane l) is point l of packet t: every load is one packet's 512 contiguous
+// bytes, the floor look-ups use the same lane -> bin map for every t, and the FFT-64 of all 8 packets is the last two passes of
+// the FFT-512 network (DFT-8 over lane bits 5..3, twiddle W64, DFT-8 over lane bits 2..0). Afterwards packet j sits in lanes
+// [8j, 8j+8), bin f = (lane & 7) + 8 c' in register c'; the overlap term of packet j is packet j-1's value 8 lanes below.
+// One block per iteration (six cross-lane radix-2 stages for one point per lane) spent the same chain of steps on 1/8 of the data.
+// Returns the number of packets taken (>= 1). P[] = unwindowed right-half values of the last packet, in the lanes of group 0.
+template <int ROLE, bool TAPC>
+__device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb,
+                                                     float2* seg2, lds_f32* cbuf, lds_u32* my_flags, const lds_u32* partner_flags, const uint32_t lane,
+                                                     const vsyn_segment sg, const SegInfo si, const uint32_t q, const uint32_t qa, const uint32_t qb,
+                                                     const uint32_t C, const uint32_t c, float* plane, const PktInfo* ip, const uint32_t epoch,
+                                                     const uint32_t prev_kind, const uint32_t prev_half, float (&P)[8], const uint32_t bseg0,
+                                                     const uint32_t sidx, const uint32_t xsl, const uint32_t posts, const uint32_t ys_stride, bool& hand_over_out) {
+  constexpr uint32_t MS = 128u, ML = 1024u;
+  const ConstHeader* H = hdr_of(A.cb);
+  // ---- the pass: packets q .. q+Jp-1 (lane j < 8 holds the descriptor of packet q + j) ----------------------------------------------
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t idx = min(q + (lane & 7u), qb - 1u);
+  const u32x4 da = ((const u32x4*)(ip + idx))[0], db = ((const u32x4*)(ip + idx))[1];
+  // (also the descriptor behind the pass: what follows its last packet)
+  const uint32_t map0 = __builtin_amdgcn_readfirstlane(db[3] & 0xFFu);
+  const bool cand = lane < 8u && q + lane < qb;
+  const uint64_t okm = __ballot(cand && !((db[3] >> 8) & 0xFFu) && !((db[2] >> 16) & 0xFFu) && (db[3] & 0xFFu) == map0);
+  const uint32_t Jp = (uint32_t)__builtin_ctzll(~okm);  // >= 1: the caller saw a valid short block at q
+  const uint32_t qn = q + Jp, p0 = sg.first_packet + q;
+  const uint32_t emit_l = q + (lane & 7u) < qa ? 0u : da[3];  // the halo emits nothing
+  // ---- loads -------------------------------------------------------------------------------------------------------------------------
+  float2 raw[8];
+  uint32_t vrow[8];
+#pragma unroll
+  for (uint32_t t = 0; t < 8; ++t) {
+    const uint32_t tc = min(t, Jp - 1u);
+    const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], tc) << 32) | __builtin_amdgcn_readlane(da[0], tc);
+    raw[t] = ((const float2*)(A.residue + off + (size_t)c * MS))[lane];
+    vrow[t] = (A.fy + ((size_t)(p0 + tc) * C + c) * ys_stride)[sidx];
+  }
+#pragma unroll
+  for (uint32_t t = 0; t < 8; ++t)
+    if (t >= Jp) raw[t] = f2(0.f, 0.f);
+  // ---- inverse coupling through the partner's image ----------------------------------------------------------------------------------
+  float2 r[8];
+  if (ROLE != 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
+    pair_post(&my_flags[0], epoch);
+    pair_wait(&partner_flags[0], epoch);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float2 oth = pxb[t * 64 + lane];
+      r[t] = ROLE == 1 ? f2(couple_mag(raw[t].x, oth.x), couple_mag(raw[t].y, oth.y)) : f2(couple_ang(oth.x, raw[t].x), couple_ang(oth.y, raw[t].y));
+    }
+    pair_post(&my_flags[1], epoch);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) r[t] = raw[t];
+  }
+  // ---- floor curve + product, packet by packet (the lane -> bin map is the same for every packet: bins 2 lane, 2 lane + 1) -------------
+  bool floor_bad = false;
+  uint32_t floor_bad_pkt = 0;
+#pragma unroll
+  for (uint32_t t = 0; t < 8; ++t) {
+    if (t >= Jp) break;
+    const uint32_t own_t = __builtin_amdgcn_readlane(db[1], t), used_t = __builtin_amdgcn_readlane(db[0], t);
+    if (!((own_t >> c) & 1u)) {
+      seg2[lane] = f2(0.f, ((used_t >> c) & 1u) ? 256.5f : 255.5f);
+    } else {
+      uint32_t v = vrow[t];
+      if (lane >= posts) v = 0;
+      const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
+      const uint64_t below = mask & ((2ull << lane) - 1ull);
+      const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
+      const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
+      const bool has_hi = above != 0ull;
+      const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
+      const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
+      const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
+      const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
+      if ((v & 0x7FFFu) > 255u) {
+        floor_bad = true;
+        floor_bad_pkt = p0 + t;
+      }
+      const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
+      const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
+      const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
+      const float ady = fabsf(y1 - y0);
+      const float a = ady * inv, b = __builtin_fmaf(-ady, x0, 0.5f) * inv;
+      seg2[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);
+    }
+    typedef float lds_vf2 __attribute__((ext_vector_type(2)));
+    const bool nocurve = !((own_t >> c) & 1u);
+    const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2;
+    const uint32_t a0 = nocurve ? seg_base : (bseg0 & 0xFFFFu), a1 = nocurve ? seg_base : (bseg0 >> 16);
+    const lds_vf2 e0 = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)a0;
+    const lds_vf2 e1 = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)a1;
+    const float xf = (float)(2u * lane);
+    const uint32_t i0 = (uint32_t)__builtin_fmaf(xf, e0.x, e0.y), i1 = (uint32_t)__builtin_fmaf(xf + 1.f, e1.x, e1.y);
+    r[t] = f2(r[t].x * T.invdb[i0], r[t].y * T.invdb[i1]);
+    if (TAPC && !nocurve) {  // feature tap "floor1 floor" (hpp:585): the table indices are the rendered curve
+      const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], t) << 32) | __builtin_amdgcn_readlane(da[0], t);
+      ((uint32_t*)(A.curve + off + (size_t)c * MS))[lane] = i0 | (i1 << 16);
+    }
+  }
+  // ---- IMDCT x 8 ------------------------------------------------------------------------------------------------------------------------
+  float2 z[8];
+  {
+    const float2 pre = T.pre_s[lane];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) z[t] = cmulf(f2(r[t].x, __shfl(r[t].y, 63 - (int)lane)), pre);  // X[127 - 2k] lives in lane 63-k
+  }
+  if (ROLE != 0) pair_wait(&partner_flags[1], epoch);  // the partner has read this wave's image: the FFT may reuse it
+  {
+    const uint32_t cl = lane & 7u, hi = lane >> 3;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xb[t * 72 + lane] = z[t];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) z[a] = xb[hi * 72 + a * 8 + cl];
+    dft8(z);
+#pragma unroll
+    for (int a = 1; a < 8; ++a) z[a] = cmulf(z[a], T.tw2[a][cl]);  // W64^(c a')
+#pragma unroll
+    for (int a = 0; a < 8; ++a) xb[a * 65 + lane] = z[a];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = xb[cl * 65 + hi * 8 + k];
+    dft8(z);
+  }
+  const uint32_t kap = lane & 7u, jo = lane >> 3;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post8[k][kap]);
+  // ---- window + overlap-add + PCM --------------------------------------------------------------------------------------------------------
+  const bool valid_o = jo < Jp, grp0 = jo == 0u;
+  const uint32_t emit = valid_o ? (uint32_t)__shfl((int)emit_l, (int)jo) : 0u;
+  float* const out = plane + (uint32_t)__shfl((int)da[2], (int)min(jo, Jp - 1u));
+  const uint32_t shift = (grp0 && prev_half == ML) ? 448u : 0u;  // after a long block the chunk starts with its 448 frames
+  float wl0[8], wl1[8], wr0[8], wr1[8], Pin[8], Pn[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    wl0[k] = T.wsl8[0][k][kap];
+    wl1[k] = T.wsl8[1][k][kap];
+    wr0[k] = wl0[k];
+    wr1[k] = wl1[k];
+    Pn[k] = k >= 4 ? z[k].y : -z[k].x;
+  }
+  {
+    const int below = (int)((lane - 8u) & 63u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float sh = __shfl(Pn[k], below);
+      Pin[k] = grp0 ? P[k] : sh;
+    }
+  }
+  if (prev_kind == K_LDS && grp0) {  // after a long block / a carry-in: the 128 windowed overlap frames are in the carry image
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t f = kap + 8u * k;
+      const uint32_t s = k >= 4 ? 2u * f - 64u : 63u - 2u * f;
+      Pin[k] = 1.f;
+      wr1[k] = cbuf[s];
+      wr0[k] = cbuf[MS - 1u - s];
+    }
+  }
+  // what follows the pass (descriptor behind it, if it was among the eight fetched; else a scalar fetch)
+  const bool last_of_segment = qn == sg.num_packets;
+  bool hand_over = false;
+  uint32_t next_emit = 0, next_out = 0;
+  if (qn < qb) {
+    uint32_t nlng, nbad;
+    if (Jp < 8u) {
+      nlng = __builtin_amdgcn_readlane((db[2] >> 16) & 0xFFu, Jp);
+      nbad = __builtin_amdgcn_readlane((db[3] >> 8) & 0xFFu, Jp);
+      next_emit = __builtin_amdgcn_readlane(da[3], Jp);
+      next_out = __builtin_amdgcn_readlane(da[2], Jp);
+    } else {
+      const PktScalars nx = pkt_load(ip + qn);
+      nlng = nx.lng;
+      nbad = nx.bad;
+      next_emit = nx.emit;
+      next_out = nx.out_pos;
+    }
+    hand_over = !nbad && nlng;
+  }
+  vmem_drain();  // loads only are in flight: finish them before the PCM stores (see vmem_drain)
+  float oh_s[4], oh_m[4], n_s[4], n_m[4];
+  const int mirror = (int)(lane ^ 7u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kh = 4 + j, kl = 3 - j;
+    const float cch = z[kh].x, ccl = -z[kl].y;
+    const float ah_s = Pin[kh] * wr1[kh], ah_m = Pin[kh] * wr0[kh], al_s = Pin[kl] * wr1[kl], al_m = Pin[kl] * wr0[kl];
+    oh_s[j] = ah_s + cch * wl0[kh];
+    oh_m[j] = ah_m + (-cch) * wl1[kh];
+    const float ol_s = al_s + ccl * wl0[kl];
+    const float ol_m = al_m + (-ccl) * wl1[kl];
+    n_s[j] = __shfl(ol_s, mirror);
+    n_m[j] = __shfl(ol_m, mirror);
+  }
+  {
+    const bool whole = emit == MS + shift && (((uintptr_t)out & 7u) == 0);
+    if (__all(whole || !valid_o)) {
+      if (valid_o) {
+        float* up = out + shift + 2u * kap;
+        float* dn = out + shift + MS - 2u - 2u * kap;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          *(float2*)(up + 16 * j) = f2(oh_s[j], n_s[j]);
+          *(float2*)(dn - 16 * j) = f2(n_m[j], oh_m[j]);
+        }
+      }
+    } else if (emit) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t s = 2u * kap + 16u * j;
+        const uint32_t f0 = s + shift, f1 = s + 1u + shift, f2m = MS - 2u - s + shift, f3m = MS - 1u - s + shift;
+        if (f0 < emit) out[f0] = oh_s[j];
+        if (f1 < emit) out[f1] = n_s[j];
+        if (f2m < emit) out[f2m] = n_m[j];
+        if (f3m < emit) out[f3m] = oh_m[j];
+      }
+    }
+  }
+  (void)next_emit;
+  (void)next_out;
+  if ((last_of_segment || hand_over) && jo == Jp - 1u) {
+    // windowed right half of the last packet in natural order: into the stream's carry buffer (segment end) or the carry image
+    // (a long block follows: its samples 448..575 meet these 128)
+    const size_t carry_half = (size_t)H->max_streams * C * ML;
+    float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * ML;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t f = kap + 8u * k;
+      const uint32_t s = k >= 4 ? 2u * f - 64u : 63u - 2u * f, sm = MS - 1u - s;
+      const float v_s = Pn[k] * wl1[k], v_m = Pn[k] * wl0[k];
+      if (last_of_segment) {
+        cout[s] = v_s;
+        cout[sm] = v_m;
+      } else {
+        cbuf[s] = v_s;
+        cbuf[sm] = v_m;
+      }
+    }
+  }
+  {
+    const int from = (int)((Jp - 1u) * 8u + kap);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[k] = __shfl(Pn[k], from);
+  }
+  if (__any(floor_bad)) {
+    if (floor_bad) raise_status(A.status, VSYN_ST_FLOOR_VALUE, floor_bad_pkt);
+    vmem_drain();
+  }
+  hand_over_out = hand_over;
+  return Jp;
+}
+
 // The whole per-wave job: the run [qa, qb) of segment g, output channel c.
 // ROLE: 0 channel c is not coupled; 1 c is the magnitude channel of the (single) coupling step; 2 c is the angle channel.
 // A coupled wave gets the partner channel's residue from the partner wave's exchange image (`pxb`) and keeps only its own
@@ -415,8 +675,6 @@ __device__ __forceinline__ void wave_unwrap(const FusedArgs& A, float2* xb_mem, 
 //             through memory, no fences),
 //   K_CARRY   from the stream's carry buffer (windowed right half in natural order) for a long block after a long carry-in.
 // `buf = 0; buf += prev*w; buf += cur*w` (hpp:1008-1017) with the same two roundings in every case.
-enum { K_REG = 0, K_LDS = 1, K_CARRY = 2 };
-__device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
 
 template <int ROLE, bool MIXED, bool TAPC>
 __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImage& T, float2* __restrict__ xb, const float2* __restrict__ pxb, float4* __restrict__ seg,
@@ -431,7 +689,6 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 #pragma unroll
   for (int k = 0; k < 8; ++k) P[k] = 0.f;
   uint32_t prev_next_long = 1;
-  float Ps = 0.f;               // MIXED: unwindowed right-half value of the previous SHORT block at this lane's point
   uint32_t prev_kind = K_REG;   // MIXED: where the overlap term comes from (wave-uniform)
   uint32_t prev_half = 0;       // MIXED: samples the previous block contributes to the current chunk's frame count: 1024 / 128 / 0
   float* const plane = A.pcm + ((size_t)g * C + c) * A.plane_stride;
@@ -459,7 +716,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   const PktInfo* const ip = A.info + __builtin_amdgcn_readfirstlane(sg.first_packet);
   if (A.ys) wave_unwrap(A, xb, lane0, sg, q0, qb, C, c);
   PktScalars pi = pkt_load(ip + q0);
-  float2 raw[8];  // own channel's residue; steady runs request it one packet ahead (mixed runs have no registers to spare for that)
+  float2 raw[8];  // own channel's residue, requested one packet ahead (mixed runs: when the next block is a long one, too)
+  bool raw_ahead = false;  // MIXED: raw[] already holds (or will hold) this packet's residue
   if (!MIXED) {
     const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * ML) + lane0;
 #pragma unroll
@@ -495,8 +753,8 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   // in both waves costs a second HBM fetch of the whole input (measured: concurrent misses on a line are not merged;
   // FETCH_SIZE x2 = 1.10 GB vs 0.55 GB per launch). my_flags[0] = "my image holds packet #n's residue",
   // my_flags[1] = "I have read the partner's image of packet #n".
-  for (uint32_t it = 0; q0 + it < qb; ++it) {
-    const uint32_t q = q0 + it;
+  uint32_t q = q0;
+  for (uint32_t it = 0; q < qb; ++it, ++q) {  // (a packed short pass advances q by more than one: `it` counts hand-off epochs)
     STAMP(0);  // loop overhead / previous iteration's tail
     // launder the lane id once per packet: keeps the lane-derived LDS/global addresses from being hoisted out of
     // the loop and pinned in VGPRs for its whole duration (recomputing them costs a few VALU ops)
@@ -514,7 +772,6 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       // waves of a pair skip it, so the hand-off counters stay in step.
 #pragma unroll
       for (int k = 0; k < 8; ++k) P[k] = 0.f;
-      Ps = 0.f;
       prev_kind = K_REG;
       prev_half = 0;
       vrow_ok = false;
@@ -525,13 +782,42 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       cur_map = pi.mapping;
       map_floor = __builtin_amdgcn_readfirstlane((uint32_t)maps[cur_map].chfloor[c]);
     }
+    if (MIXED && !lng) {
+      // ---- short blocks: up to eight consecutive ones as one pass (fused_short_pass) ---------------------------------------------
+      if (cur_floor != (int)map_floor) {  // wave-uniform: the short floor's lane constants
+        const FloorConst* fc = floors + map_floor;
+        posts = __builtin_amdgcn_readfirstlane(fc->posts);
+        const uint8_t* bs = A.binseg + (size_t)map_floor * ML;
+        const uint32_t seg_base0 = (uint32_t)(uintptr_t)(lds_u32*)seg;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));
+          bseg[t] = (seg_base0 + 8u * (two & 0xFFu)) | ((seg_base0 + 8u * (two >> 8)) << 16);
+        }
+        const bool in = lane < posts;
+        sidx = in ? fc->sorted_idx[lane] : 0u;
+        xsl = in ? fc->xs_sorted[lane] : 0u;
+        cur_floor = (int)map_floor;
+        vmem_drain();
+      }
+      bool ho = false;
+      const uint32_t Jp = fused_short_pass<ROLE, TAPC>(A, T, xb, pxb, (float2*)seg, cbuf, my_flags, partner_flags, lane, sg, si, q, qa, qb, C, c, plane, ip, it + 1u,
+                                                 prev_kind, prev_half, P, bseg[0], sidx, xsl, posts, ys_stride, ho);
+      prev_kind = ho ? K_LDS : K_REG;
+      prev_half = 128u;
+      prev_next_long = 0u;
+      vrow_ok = false;
+      q += Jp - 1u;
+      pi = pkt_load(ip + min(q + 1u, qb - 1u));
+      continue;
+    }
 
     // ---- residue: bins (2k, 2k+1), k = lane + 64 t (requested one packet ahead, see below); inverse coupling keeps
     //      this wave's side only (hpp:1213-1241) ----------------------------------------------------------------
     float2 r[8];
     // L = rows of the block: all 8 (long) or the first (short); called with a literal so that each copy is straight-line code
     auto residue_rows = [&](const bool L) {
-      if (MIXED) {
+      if (MIXED && !raw_ahead) {
         const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * (L ? ML : 128u)) + lane;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -568,6 +854,17 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * ML) + lane;  // one 64-bit add, immediate offsets
 #pragma unroll
       for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
+    } else {
+#ifdef VSYN_MIXED_PREFETCH
+      // Measured (config 4): the 16 registers this keeps live across the floor product, FFT and overlap do not exist in the 128-VGPR
+      // mixed path — 224 B/lane of scratch, kernel 0.068 -> 0.121 ms. Off; it needs a launch of its own at 3 waves per SIMD.
+      raw_ahead = has_next && nlng && !pin.bad;  // (this point is only reached by long blocks: short ones take fused_short_pass)
+      if (raw_ahead) {
+        const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * ML) + lane;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
+      }
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -848,48 +1145,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         vmem_drain();  // rare block: rejoin with nothing of its own pending (see vmem_drain)
       }
     } else {
-      // ---- short block: one complex point per lane ------------------------------------------------------------
-      floor_product(false);
-      const float im = __shfl(r[0].y, 63 - (int)lane);  // X[127 - 2k] lives in lane 63-k
-      float2 z = cmulf(f2(r[0].x, im), T.pre_s[lane]);
-      if (ROLE != 0) pair_wait(&partner_flags[1], it + 1);  // the partner has read this wave's image: the next packet may reuse it
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {  // radix-2 decimation in frequency across lanes: partner l ^ d, d = 32 .. 1
-        const int d = 32 >> i;
-        const float ox = __shfl_xor(z.x, d), oy = __shfl_xor(z.y, d);
-        const bool upper = (lane & (uint32_t)d) != 0;
-        const float2 sum = f2(z.x + ox, z.y + oy);
-        const float2 dif = cmulf(f2(ox - z.x, oy - z.y), T.tws[i][lane]);  // (lower - upper) * W, evaluated in the upper lane
-        z = upper ? dif : sum;
-      }
-      const float2 d = cmulf(z, T.post_s[lane]);
-      const uint32_t m = bitrev6(lane);
-      const bool hi = m >= 32u;
-      const uint32_t s = hi ? 2u * m - 64u : 63u - 2u * m, sm = 127u - s;
-      const float cc = hi ? d.x : -d.y, pn = hi ? d.y : -d.x;
-      // overlap terms: a short block before (same lanes), or the carry image (after a long block / a carry-in)
-      float a_s, a_m;
-      if (prev_kind == K_LDS) {
-        a_s = cbuf[s];
-        a_m = cbuf[sm];
-      } else {
-        a_s = Ps * T.wsl[1][lane];
-        a_m = Ps * T.wsl[0][lane];
-      }
-      const uint32_t shift = prev_half == ML ? 448u : 0u;  // after a long block the chunk starts with its 448 frames
-      const float o_s = a_s + cc * T.wsl[0][lane], o_m = a_m + (-cc) * T.wsl[1][lane];
-      if (s + shift < emit) out[s + shift] = o_s;
-      if (sm + shift < emit) out[sm + shift] = o_m;
-      Ps = pn;
-      if (last_of_segment) {
-        const size_t carry_half = (size_t)H->max_streams * C * ML;
-        float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * ML;
-        cout[s] = pn * T.wsl[1][lane];
-        cout[sm] = pn * T.wsl[0][lane];
-      } else if (hand_over) {
-        cbuf[s] = pn * T.wsl[1][lane];
-        cbuf[sm] = pn * T.wsl[0][lane];
-      }
+      // (short blocks of the mixed-block path are taken by fused_short_pass above)
     }
     if (MIXED) {
       prev_kind = hand_over ? K_LDS : K_REG;
@@ -1102,6 +1358,13 @@ static inline hipError_t fused_tables_create(const ConstHeader& H, const uint8_t
         im.wsl[0][l] = win0[sidx];
         im.wsl[1][l] = win0[127 - sidx];
       }
+      for (uint32_t cc = 0; cc < 8; ++cc)
+        for (uint32_t a = 0; a < 8; ++a) {
+          const uint32_t f = a + 8 * cc, s8 = cc >= 4 ? 2 * f - 64 : 63 - 2 * f;
+          im.post8[cc][a] = post0[f];
+          im.wsl8[0][cc][a] = win0[s8];
+          im.wsl8[1][cc][a] = win0[127 - s8];
+        }
     }
     e = hipMalloc((void**)&ft->d_lds, sizeof(FusedLdsImage));
     if (e != hipSuccess) return e;
