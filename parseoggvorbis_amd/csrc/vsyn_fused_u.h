@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "vsyn_device.h"
+#include "vsyn_staged.h"
 #include "vsyn_fused.h"
 
 struct ULdsSize {           // one block size; every table in exactly the order the lanes read it
@@ -50,7 +51,11 @@ struct UArgs {
   const ULdsImage* img;
   uint32_t wave_bytes;      // per-wave LDS block size (multiple of 16)
   uint32_t table_bytes;     // sizeof(ULdsImage) rounded up
+  uint32_t role_mode;       // 0 no coupling anywhere, 1 / 2 one step (mag 0, ang 1) / (mag 1, ang 0) in every mapping of a stereo stream:
+                            // the two channel waves swap rows pairwise; 3 anything else (<= U_MAX_CH channels, any coupling list per
+                            // mapping): the channel waves of a run replay the steps in place, in order
 };
+#define U_MAX_CH 12u
 
 __device__ __forceinline__ void u_dft4(float2& x0, float2& x1, float2& x2, float2& x3) {  // natural order, forward
   const float2 a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = mul_mi(csub(x1, x3));
@@ -90,8 +95,9 @@ struct UPass {
 };
 
 template <int ROLE>
-__device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, uint8_t* wmem, const uint8_t* pmem, const uint32_t lane, const uint32_t g,
-                                      const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C, const uint32_t c) {
+__device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, uint8_t* wmem, const uint8_t* pmem, const uint32_t wave_bytes, const uint32_t lane,
+                                      const uint32_t g, const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C,
+                                      const uint32_t c) {
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
   float2* const xb = (float2*)wmem;
@@ -226,7 +232,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
   if (A.ys) wave_unwrap(A, xb, lane, sg, q0, qb, C, c);
   fetch_info(q0);
   vmem_drain();
-  uint32_t it = 0, qnext = q0;
+  uint32_t it = 0, qnext = q0, steps_done = 0;
   for (;;) {
     // (Forming the NEXT pass early and requesting its residue a pass ahead was measured: 24 more live registers, no gain at the 8-12
     // waves per CU this kernel runs at — 0.221 vs 0.218 ms per 65 536 n = 1024 packets without spills, slower with them.)
@@ -252,7 +258,44 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 #pragma unroll
     for (int t = 0; t < 8; ++t)
       if (((64u * t + lane) >> LG) >= Jp) raw[t] = f2(0.f, 0.f);  // elements beyond the pass's last packet
-    if (ROLE != 0) {
+    if (ROLE == 3) {
+      // General case: the C channel waves of this run (adjacent waves, channel 0 first) put their rows into their images; the coupling
+      // steps of the pass's mapping are then replayed IN PLACE, last step first (hpp:1213-1241), each by the wave of its magnitude
+      // channel, one after the other; finally every wave reads its own rows back. Two monotonic counters in channel 0's flag block:
+      // [2] rows in place (one count per wave and pass), [3] steps done.
+      uint8_t* const g0 = wmem - (size_t)c * wave_bytes;
+      lds_u32* const gfl = (lds_u32*)(g0 + U_FLAG_OFF);
+      const MapConst* mc = maps + cur.map;
+      const uint32_t ncoup = __builtin_amdgcn_readfirstlane(mc->ncoup);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
+      if (ncoup) {
+        if (lane == 0) __atomic_fetch_add(gfl + 2, 1u, __ATOMIC_RELAXED);
+        for (uint32_t i = 0; i < ncoup; ++i) {
+          const uint32_t k = ncoup - 1u - i;
+          const uint32_t cm = __builtin_amdgcn_readfirstlane((uint32_t)mc->coup[2 * k]), ca = __builtin_amdgcn_readfirstlane((uint32_t)mc->coup[2 * k + 1]);
+          if (c == cm) {
+            pair_wait(gfl + 2, C * it);
+            pair_wait(gfl + 3, steps_done + i);
+            float2* im = (float2*)(g0 + (size_t)cm * wave_bytes);
+            float2* ia = (float2*)(g0 + (size_t)ca * wave_bytes);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              float2 vm = im[t * 64 + lane], va = ia[t * 64 + lane];
+              inverse_couple(vm.x, va.x);
+              inverse_couple(vm.y, va.y);
+              im[t * 64 + lane] = vm;
+              ia[t * 64 + lane] = va;
+            }
+            pair_post(gfl + 3, steps_done + i + 1u);
+          }
+        }
+        pair_wait(gfl + 3, steps_done + ncoup);
+        steps_done += ncoup;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) r[t] = xb[t * 64 + lane];
+    } else if (ROLE != 0) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
       pair_post(&my_flags[0], it);
@@ -267,12 +310,13 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 #pragma unroll
       for (int t = 0; t < 8; ++t) r[t] = raw[t];
     }
+    (void)steps_done;
     // coded rows of this pass, two per register (the row registers are about to be reused)
     uint32_t vcur[U_MAX_J / 2];
 #pragma unroll
     for (uint32_t j = 0; j < U_MAX_J / 2; ++j) vcur[j] = (vrow[2 * j] & 0xFFFFu) | (vrow[2 * j + 1] << 16);
 
-    if (ROLE != 0) pair_wait(&partner_flags[1], it);  // the partner has read this wave's image: it may be reused (floor factors, FFT)
+    if (ROLE == 1 || ROLE == 2) pair_wait(&partner_flags[1], it);  // the partner has read this wave's image: it may be reused (floor factors, FFT)
 
     // ---- floor curve, packet by packet, in bin order (hpp:563-589) -----------------------------------------------------------------
     bool floor_bad = false;
@@ -611,17 +655,18 @@ __global__ void __launch_bounds__(U_MAX_THREADS) vsyn_fused_u_kernel(const UArgs
     for (uint32_t i = threadIdx.x; i < sizeof(ULdsImage) / 16; i += blockDim.x) dst[i] = src[i];
   }
   uint8_t* wmem = u_lds + U.table_bytes + wave * U.wave_bytes;
-  if (lane < 2) ((uint32_t*)(wmem + U_FLAG_OFF))[lane] = 0u;
+  if (lane < 4) ((uint32_t*)(wmem + U_FLAG_OFF))[lane] = 0u;
   __syncthreads();
   if (!active) return;
   const ULdsImage& T = *(const ULdsImage*)u_lds;
-  const uint32_t mag = A.coupling_mode == 1 ? 0u : 1u;
-  const int role = (A.coupling_mode == 0 || C < 2) ? 0 : (c == mag ? 1 : 2);
-  const uint32_t pw = role ? (wave ^ 1u) : wave;
+  const uint32_t mag = U.role_mode == 1 ? 0u : 1u;
+  const int role = U.role_mode == 3 ? 3 : ((U.role_mode == 0 || C < 2) ? 0 : (c == mag ? 1 : 2));
+  const uint32_t pw = (role == 1 || role == 2) ? (wave ^ 1u) : wave;
   const uint8_t* pmem = u_lds + U.table_bytes + pw * U.wave_bytes;
-  if (role == 0) u_run<0>(A, T, wmem, pmem, lane, g, sg, si, qa, qb, C, c);
-  else if (role == 1) u_run<1>(A, T, wmem, pmem, lane, g, sg, si, qa, qb, C, c);
-  else u_run<2>(A, T, wmem, pmem, lane, g, sg, si, qa, qb, C, c);
+  if (role == 0) u_run<0>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else if (role == 1) u_run<1>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else if (role == 2) u_run<2>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else u_run<3>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -629,25 +674,30 @@ __global__ void __launch_bounds__(U_MAX_THREADS) vsyn_fused_u_kernel(const UArgs
 // ------------------------------------------------------------------------------------------------
 struct UTables {
   ULdsImage* d_img = nullptr;
-  uint32_t wave_bytes = 0, table_bytes = 0, waves_per_block = 0, waves_per_cu = 0;
+  uint32_t wave_bytes = 0, table_bytes = 0, waves_per_block = 0, waves_per_cu = 0, role_mode = 0;
 };
 
 static inline bool u_supported(const ConstHeader& H, const uint8_t* host_const) {
-  if (H.bs[1] > 2048 || H.channels > 2) return false;
+  if (H.bs[1] > 2048 || H.channels > U_MAX_CH) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
   for (uint32_t f = 0; f < H.num_floors; ++f)
     if (fl[f].posts > 64) return false;
-  // one coupling structure for every mapping (the role of a wave is fixed for the launch)
+  return true;
+}
+
+// 0 / 1 / 2: stereo or mono with the same (at most one) coupling step in every mapping — the pairwise row swap; 3: the general replay
+static inline uint32_t u_role_mode(const ConstHeader& H, const uint8_t* host_const) {
   const MapConst* mp = (const MapConst*)(host_const + H.off_map);
+  if (H.channels > 2) return 3;
   int want = -2;
   for (uint32_t k = 0; k < H.num_modes; ++k) {
     const MapConst& m = mp[H.mode_mapping[k]];
     const int cur = m.ncoup == 0 ? 0 : (m.ncoup == 1 ? (m.coup[0] == 0 ? 1 : 2) : -1);
-    if (cur < 0) return false;
+    if (cur < 0) return 3;
     if (want == -2) want = cur;
-    else if (want != cur) return false;
+    else if (want != cur) return 3;
   }
-  return true;
+  return want < 0 ? 0u : (uint32_t)want;
 }
 
 static inline void u_fill_size(const ConstHeader& H, const uint8_t* host_const, int b, ULdsSize& S) {
@@ -702,8 +752,12 @@ static inline hipError_t u_tables_create(const ConstHeader& H, const uint8_t* ho
   ut->wave_bytes = (U_CBUF_OFF + cbuf + 15u) & ~15u;
   const uint32_t budget = 156u * 1024u;
   uint32_t w = (budget - ut->table_bytes) / ut->wave_bytes;
-  w = std::min<uint32_t>(U_MAX_THREADS / 64u, w) & ~1u;
-  ut->waves_per_block = std::max<uint32_t>(2u, w);
+  w = std::min<uint32_t>(U_MAX_THREADS / 64u, w);
+  ut->role_mode = u_role_mode(H, host_const);
+  // the channel waves of a run share a workgroup: a multiple of the channel count (of 2 for the pairwise swap)
+  const uint32_t grp = ut->role_mode == 3 ? H.channels : 2u;
+  if (w < grp) return hipErrorInvalidValue;
+  ut->waves_per_block = w / grp * grp;
   ut->waves_per_cu = ut->waves_per_block;  // one workgroup per CU (the tables take a quarter of the LDS)
   e = hipFuncSetAttribute((const void*)vsyn_fused_u_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(ut->table_bytes + ut->waves_per_block * ut->wave_bytes));
@@ -725,6 +779,7 @@ static inline hipError_t u_launch(const ConstHeader& H, const UTables& ut, const
   u.img = ut.d_img;
   u.wave_bytes = ut.wave_bytes;
   u.table_bytes = ut.table_bytes;
+  u.role_mode = ut.role_mode;
   const uint32_t wpb = ut.waves_per_block;
   dim3 grid((uint32_t)((units + wpb - 1) / wpb));
   vsyn_fused_u_kernel<<<grid, wpb * 64, ut.table_bytes + wpb * ut.wave_bytes, s>>>(u);

@@ -472,3 +472,31 @@ def test_submit_flags_may_alternate_between_submits():
             got = d["pcm"][s, :, :n].cpu().numpy()
             assert np.abs(got - want["pcm"][s][:, at:at + n]).max() < TOL * max(1.0, float(np.abs(want["pcm"]).max())), (s, k)
             at += n
+
+
+MULTI = [
+    # C, bs0, bs1, couplings
+    (6, 128, 1024, [(0, 1), (0, 2), (3, 4)]),   # 5.1-style: three steps, channel 0 in two of them (order matters)
+    (6, 256, 2048, [(0, 2), (3, 4), (1, 0)]),
+    (3, 256, 2048, [(1, 2)]),
+    (5, 512, 512, []),
+    (4, 64, 256, [(0, 1), (2, 3), (0, 2), (1, 3)]),
+    (2, 256, 1024, [(1, 0), (0, 1)]),            # stereo with a two-step chain: not the pairwise swap
+]
+
+
+@pytest.mark.parametrize("C,bs0,bs1,coup", MULTI)
+def test_multichannel_and_chained_couplings_stay_fused(C, bs0, bs1, coup):
+    """More than two channels / chained coupling steps (hpp:1213-1241, 765-814) on the size-generic fused kernel: the channel waves
+    of a run replay the steps in place. Run class asserted; PCM and posts against the oracle, fused == staged within the gate."""
+    base = fixture_like_spec(1, bs0, bs1)
+    spec = SetupSpec(C, bs0, bs1, base.floors, [(coup, [0] * C), (coup, [1] * C)], [(0, 0), (1, 1)])
+    b = synth_batch(spec, 3, 29, "mixed", seed=C * 13 + bs0, unused_frac=0.25, granule_last=True)
+    gpu = binding.Synth(spec, max_streams=3)
+    assert gpu.fused_paths & 2, gpu.fused_paths
+    want = ob.OracleSynth(spec, 3).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    check(got, want)
+    gpu.reset()
+    staged = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED)
+    check(staged, want)
