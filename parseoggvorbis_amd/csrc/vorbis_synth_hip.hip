@@ -130,6 +130,7 @@ struct vsyn_handle {
   DevBuf<uint32_t> ws_segmap[2];
   DevBuf<uint16_t> ws_fy[2];
   DevBuf<uint8_t> ws_runcls[2];
+  DevBuf<LayoutChunk> ws_chunks;   // look-back records of the chunked layout scan (segments beyond LAYOUT_CHUNK_PACKETS)
   DevBuf<float> ws_env, ws_blk;
   // host-submit staging
   DevBuf<vsyn_packet> st_pk;
@@ -437,6 +438,7 @@ void vsyn_destroy(vsyn_handle* h) {
   if (h->d_carry) (void)hipFree(h->d_carry);
   if (h->d_status) (void)hipFree(h->d_status);
   h->ws_count.release();
+  h->ws_chunks.release();
   for (int b = 0; b < 2; ++b) {
     h->ws_list[b].release(); h->ws_info[b].release(); h->ws_seg[b].release(); h->ws_segmap[b].release(); h->ws_fy[b].release(); h->ws_runcls[b].release();
   }
@@ -589,14 +591,22 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   // that order has to be stated.
   if (h->pre_done_valid[wb ^ 1u] && h->last_pre_stream != ps) HIPCHK(hipStreamWaitEvent(ps, h->ev_pre_done[wb ^ 1u], 0));
   {
-    // (a 1024-thread block cannot sit next to a synthesis workgroup: it pays only when the serial scan of a very long segment
-    //  would otherwise dominate — 1 x 65536 packets: 105 -> 128 M packets/s, but 16 x 4096: 221 -> 191 M)
-    const uint32_t lt = max_seg_packets <= LAYOUT_SHORT_PACKETS ? LAYOUT_THREADS_SHORT
-                        : (max_seg_packets > LAYOUT_LONG_PACKETS ? LAYOUT_THREADS_LONG : LAYOUT_THREADS);
-    const uint32_t bitmap_packets = std::min<uint32_t>(max_seg_packets, LAYOUT_BITMAP_PACKETS);
-    vsyn_layout_kernel<<<S, lt, layout_lds_bytes(lt, bitmap_packets), ps>>>(h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len,
-                                                                          h->d_status, R, force_staged ? 0u : fmask, list, cnt, cnt_next, segmap,
-                                                                          h->ws_runcls[wb].p, runs_per_seg, bitmap_packets);
+    // segments longer than LAYOUT_CHUNK_PACKETS are scanned in chunks (a multiple of R each) chained by a look-back; the usual batch
+    // has one chunk per segment
+    const uint32_t chunk_packets = max_seg_packets <= LAYOUT_CHUNK_PACKETS ? runs_per_seg * R : (LAYOUT_CHUNK_PACKETS + R - 1u) / R * R;
+    const uint32_t chunks_per_seg = (max_seg_packets + chunk_packets - 1u) / chunk_packets;
+    const uint32_t lt = std::min(chunk_packets, max_seg_packets) <= LAYOUT_SHORT_PACKETS ? LAYOUT_THREADS_SHORT : LAYOUT_THREADS;
+    if (chunks_per_seg > 1) {
+      const size_t need = (size_t)S * chunks_per_seg;
+      if (need > h->ws_chunks.cap) {
+        HIPCHK(h->ws_chunks.ensure(need));
+        HIPCHK(hipMemsetAsync(h->ws_chunks.p, 0, h->ws_chunks.cap * sizeof(LayoutChunk), ps));  // flags are epoch-tagged: cleared once
+      }
+    }
+    if ((uint64_t)S * chunks_per_seg > 0x7FFFFFFFull) return fail(err, VSYN_ERR_INVALID, "too many layout chunks");
+    vsyn_layout_kernel<<<S * chunks_per_seg, lt, layout_lds_bytes(lt, chunk_packets), ps>>>(
+        h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len, h->d_status, R, force_staged ? 0u : fmask, list, cnt,
+        cnt_next, segmap, h->ws_runcls[wb].p, runs_per_seg, chunk_packets, chunks_per_seg, h->ws_chunks.p, h->submit_count);
   }
   // Floor unwrap: a kernel of its own. The consuming waves can do it themselves (wave_unwrap in vsyn_fused.h, VSYN_UNWRAP_IN_WAVE=1,
   // only when every run of the batch is taken by a fused kernel) — measured on config 3: the 4096 waves then all spend their first

@@ -88,6 +88,22 @@ typedef __attribute__((address_space(3))) u_u32x4 u_lds_u32x4;
 typedef __attribute__((address_space(3))) u_f32x4 u_lds_f32x4;
 typedef __attribute__((address_space(3))) u_f32x2 u_lds_f32x2;
 
+// Wait on a counter of the channel group, bounded: the waves of a group always reach the same counts (same packets, same mappings),
+// so the bound is never met — but a wave that waited for ever would take the device down with it, so after ~2 s it flags the batch
+// (VSYN_ST_BAD_SEGMENT) and goes on.
+__device__ __forceinline__ void group_wait(const lds_u32* flag, uint32_t v, DevStatus* status) {
+  asm volatile("" ::: "memory");
+  uint32_t spins = 0;
+  while (*(const volatile lds_u32*)flag < v) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1u << 24)) {
+      if ((threadIdx.x & 63u) == 0) atomicOr(&status->flags, VSYN_ST_BAD_SEGMENT);
+      break;
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+
 // what a wave knows about one pass (all wave-uniform)
 struct UPass {
   uint32_t q, Jp, LG, lng, map, last_widx, qn, buf;
@@ -232,7 +248,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
   if (A.ys) wave_unwrap(A, xb, lane, sg, q0, qb, C, c);
   fetch_info(q0);
   vmem_drain();
-  uint32_t it = 0, qnext = q0, steps_done = 0;
+  uint32_t it = 0, qnext = q0, steps_done = 0, coupled_passes = 0;
   for (;;) {
     // (Forming the NEXT pass early and requesting its residue a pass ahead was measured: 24 more live registers, no gain at the 8-12
     // waves per CU this kernel runs at — 0.221 vs 0.218 ms per 65 536 n = 1024 packets without spills, slower with them.)
@@ -270,13 +286,14 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 #pragma unroll
       for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
       if (ncoup) {
+        ++coupled_passes;  // (passes of a mapping without coupling steps take no part in the counters)
         if (lane == 0) __atomic_fetch_add(gfl + 2, 1u, __ATOMIC_RELAXED);
         for (uint32_t i = 0; i < ncoup; ++i) {
           const uint32_t k = ncoup - 1u - i;
           const uint32_t cm = __builtin_amdgcn_readfirstlane((uint32_t)mc->coup[2 * k]), ca = __builtin_amdgcn_readfirstlane((uint32_t)mc->coup[2 * k + 1]);
           if (c == cm) {
-            pair_wait(gfl + 2, C * it);
-            pair_wait(gfl + 3, steps_done + i);
+            group_wait(gfl + 2, C * coupled_passes, A.status);
+            group_wait(gfl + 3, steps_done + i, A.status);
             float2* im = (float2*)(g0 + (size_t)cm * wave_bytes);
             float2* ia = (float2*)(g0 + (size_t)ca * wave_bytes);
 #pragma unroll
@@ -290,7 +307,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
             pair_post(gfl + 3, steps_done + i + 1u);
           }
         }
-        pair_wait(gfl + 3, steps_done + ncoup);
+        group_wait(gfl + 3, steps_done + ncoup, A.status);
         steps_done += ncoup;
       }
 #pragma unroll
@@ -311,6 +328,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
       for (int t = 0; t < 8; ++t) r[t] = raw[t];
     }
     (void)steps_done;
+    (void)coupled_passes;
     // coded rows of this pass, two per register (the row registers are about to be reused)
     uint32_t vcur[U_MAX_J / 2];
 #pragma unroll

@@ -49,19 +49,18 @@ __device__ __forceinline__ uint32_t run_class(const ConstHeader* H, const vsyn_p
   return 0;
 }
 
-// The same decision from a bitmap (bit q = packet q of the segment is a valid long block), for segments of up to
-// LAYOUT_BITMAP_PACKETS packets: pass B sets the bits while it has the packet descriptors in registers, so that classifying a
-// run is a few LDS words instead of a serial walk over R+1 descriptors in global memory (which was most of this kernel's time,
-// and this kernel's workgroups sit on wave slots the synthesis kernel of the previous submit is waiting for).
-#define LAYOUT_BITMAP_PACKETS 65536u
-__device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_t qa, uint32_t qb, uint32_t carry_n, uint32_t ok_mask) {
+// The same decision from a bitmap in LDS (bit = a valid long block): bits [first, end) are the run's packets, bit first - 1 its
+// one-packet halo (for the segment's first run there is none: the carry-in decides). Classifying a run is then a few LDS words
+// instead of a serial walk over R+1 descriptors in global memory (which was most of the layout kernel's time, and its
+// workgroups sit on wave slots the synthesis kernel of the previous submit is waiting for).
+__device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_t first, uint32_t end, uint32_t carry_n, uint32_t ok_mask, bool seg_start) {
   if (!ok_mask) return 0;
-  bool all_long = !(qa == 0 && carry_n);
-  const uint32_t lo = qa ? qa - 1 : 0;  // one-packet halo
-  for (uint32_t w = lo >> 5; all_long && w <= ((qb - 1u) >> 5); ++w) {
+  bool all_long = !(seg_start && carry_n);
+  const uint32_t lo = seg_start ? first : first - 1u;  // one-packet halo
+  for (uint32_t w = lo >> 5; all_long && w <= ((end - 1u) >> 5); ++w) {
     uint32_t need = 0xFFFFFFFFu;
     if (w == (lo >> 5)) need &= 0xFFFFFFFFu << (lo & 31u);
-    if (w == ((qb - 1u) >> 5)) need &= 0xFFFFFFFFu >> (31u - ((qb - 1u) & 31u));
+    if (w == ((end - 1u) >> 5)) need &= 0xFFFFFFFFu >> (31u - ((end - 1u) & 31u));
     all_long = (bits[w] & need) == need;
   }
   if (all_long && (ok_mask & 1u)) return 1;
@@ -69,39 +68,54 @@ __device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_
   return 0;
 }
 
-// Block size LAYOUT_THREADS, or one wavefront per segment (LAYOUT_THREADS_SHORT) when no segment of the batch has more than
+// A segment is scanned in CHUNKS of chunk_packets packets (a multiple of the run length R, so that a run never straddles two
+// chunks), one workgroup per (segment, chunk). With one chunk per segment — every segment of the batch is at most
+// LAYOUT_CHUNK_PACKETS long: the usual case — nothing below about look-back runs. Longer segments (ONE long stream is the second
+// partitioning of SURVEY 8e) chain their chunks with a decoupled look-back: a chunk publishes the aggregate of its own packets, walks
+// back over its predecessors' records until it meets one that already holds an inclusive prefix, and publishes its own inclusive
+// prefix. The serial scan of one workgroup per segment made 1 x 65 536 packets run at half the rate of 64 x 1024.
+// Block size LAYOUT_THREADS, or one wavefront per chunk (LAYOUT_THREADS_SHORT) when no chunk of the batch has more than
 // LAYOUT_SHORT_PACKETS packets: a batch of thousands of short streams would otherwise put four nearly idle waves per segment
 // on the chip, next to the synthesis kernel. Dynamic LDS: layout_lds_bytes().
 #define LAYOUT_THREADS 256
 #define LAYOUT_THREADS_SHORT 64
-#define LAYOUT_THREADS_LONG 1024   /* only for batches with a segment beyond LAYOUT_LONG_PACKETS: few, very long streams */
-#define LAYOUT_LONG_PACKETS 16384u
 #define LAYOUT_SHORT_PACKETS 256u
-static inline __host__ __device__ size_t layout_lds_bytes(uint32_t threads, uint32_t bitmap_packets) {
-  return (size_t)threads * (sizeof(AbsScan) + sizeof(uint64_t)) + (size_t)((bitmap_packets + 31u) / 32u) * 4u + 16u;
+#define LAYOUT_CHUNK_PACKETS 4096u
+struct LayoutChunk {          // look-back record of one (segment, chunk); 48 bytes
+  uint32_t flag;              // epoch * 4 + 1: aggregate valid, + 2: inclusive prefix valid (no clearing between submits)
+  uint32_t pad;
+  int64_t agg_val, inc_val;   // AbsScan of the chunk's own packets / of everything up to its end
+  uint64_t agg_res, inc_res;  // residue floats likewise
+  uint32_t agg_set, inc_set;
+};
+static inline __host__ __device__ size_t layout_lds_bytes(uint32_t threads, uint32_t chunk_packets) {
+  return (size_t)threads * (sizeof(AbsScan) + sizeof(uint64_t)) + (size_t)((chunk_packets + 1u + 31u) / 32u) * 4u + 16u;
 }
-__global__ void __launch_bounds__(LAYOUT_THREADS_LONG)
+__global__ void __launch_bounds__(LAYOUT_THREADS)
 vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet* __restrict__ pk, uint32_t S,
                    const vsyn_segment* __restrict__ segs, uint64_t plane_stride, PktInfo* __restrict__ info,
                    SegInfo* __restrict__ sinfo, StreamState* __restrict__ state, uint32_t* __restrict__ emit_len,
                    DevStatus* __restrict__ status, uint32_t R, uint32_t fused_ok, uint32_t* __restrict__ staged_list,
                    uint32_t* __restrict__ staged_count, uint32_t* __restrict__ next_count, uint32_t* __restrict__ seg_of_pkt,
-                   uint8_t* __restrict__ run_cls, uint32_t runs_per_seg, uint32_t bitmap_packets) {
+                   uint8_t* __restrict__ run_cls, uint32_t runs_per_seg, uint32_t chunk_packets, uint32_t chunks_per_seg,
+                   LayoutChunk* __restrict__ chunks, uint32_t epoch) {
   const ConstHeader* H = hdr_of(cb);
-  const uint32_t g = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
+  const uint32_t g = blockIdx.x / chunks_per_seg, ch = blockIdx.x % chunks_per_seg, t = threadIdx.x, NT = blockDim.x;
   if (g >= S) return;
-  if (g == 0 && t == 0) *next_count = 0;  // the other submit parity's list counter (no memset node needed)
+  if (blockIdx.x == 0 && t == 0) *next_count = 0;  // the other submit parity's list counter (no memset node needed)
   const vsyn_segment sg = segs[g];
   const bool seg_ok = sg.stream < H->max_streams && (uint64_t)sg.first_packet + sg.num_packets <= P && (sg.residue_off & 3) == 0;
+  const uint32_t cs = ch * chunk_packets;  // first packet of this chunk
+  const uint32_t runs_per_chunk = chunk_packets / R;
   if (!seg_ok) {
-    if (t == 0) {
+    if (t == 0 && ch == 0) {
       raise_status(status, VSYN_ST_BAD_SEGMENT, sg.first_packet < P ? sg.first_packet : 0);
       sinfo[g] = SegInfo{0, 0, 0, 0};
     }
-    for (uint32_t r = t; r < runs_per_seg; r += NT) run_cls[(size_t)g * runs_per_seg + r] = 0xFFu;
+    for (uint32_t r = ch * runs_per_chunk + t; r < min(runs_per_seg, (ch + 1u) * runs_per_chunk); r += NT) run_cls[(size_t)g * runs_per_seg + r] = 0xFFu;
     // mark every packet we may safely touch as bad so later kernels skip it
     if ((uint64_t)sg.first_packet + sg.num_packets <= P)
-      for (uint32_t q = t; q < sg.num_packets; q += NT) {
+      for (uint32_t q = cs + t; q < min(sg.num_packets, cs + chunk_packets); q += NT) {
         PktInfo pi = {};
         pi.bad = 1;
         pi.n = (uint16_t)H->bs[0];
@@ -110,6 +124,13 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     return;
   }
   const uint32_t C = H->channels, num = sg.num_packets;
+  // runs of this chunk that lie beyond the segment's end
+  if (cs >= num && !(ch == 0)) {
+    for (uint32_t r = ch * runs_per_chunk + t; r < min(runs_per_seg, (ch + 1u) * runs_per_chunk); r += NT) run_cls[(size_t)g * runs_per_seg + r] = 0xFFu;
+    return;
+  }
+  const uint32_t cn = min(num, cs + chunk_packets) - min(num, cs);  // packets of this chunk
+  const bool last_chunk = cs + cn >= num;
   StreamState st0 = state[sg.stream];
   const bool reset = (sg.flags & VSYN_SEG_RESET) != 0;
   const uint32_t carry_n = (!reset && st0.has_prev) ? st0.prev_n : 0;
@@ -118,16 +139,17 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // layout_lds_bytes(): scan arrays [NT], then the bitmap
   AbsScan* s_abs = (AbsScan*)s_dyn;
   uint64_t* s_res = (uint64_t*)(s_dyn + (size_t)NT * sizeof(AbsScan));
-  uint32_t* s_longbits = (uint32_t*)(s_dyn + (size_t)NT * (sizeof(AbsScan) + sizeof(uint64_t)));  // [min(max_seg, LAYOUT_BITMAP_PACKETS) / 32]
-  const bool use_bits = num <= bitmap_packets;  // (the launch sized the bitmap for the longest segment it was told about)
-  if (use_bits)
-    for (uint32_t w = t; w < (num + 31u) / 32u; w += NT) s_longbits[w] = 0u;
+  // bit 0: the packet in front of the chunk (the first run's halo), bit 1 + i: packet cs + i — set = a valid long block
+  uint32_t* s_longbits = (uint32_t*)(s_dyn + (size_t)NT * (sizeof(AbsScan) + sizeof(uint64_t)));
+  for (uint32_t w = t; w < (cn + 1u + 31u) / 32u; w += NT) s_longbits[w] = 0u;
   __shared__ int64_t s_abs_end;
   __shared__ uint32_t s_last_n;
+  __shared__ AbsScan s_chunk_ex;   // exclusive prefix of this chunk (everything before it in the segment)
+  __shared__ uint64_t s_chunk_rex;
 
-  const uint32_t per = (num + NT - 1) / NT;
-  const uint32_t qb = min(num, t * per), qe = min(num, qb + per);
-  const vsyn_packet* spk = pk + sg.first_packet;
+  const uint32_t per = (cn + NT - 1) / NT;
+  const uint32_t qb = min(cn, t * per), qe = min(cn, qb + per);  // this thread's packets, relative to the chunk
+  const vsyn_packet* spk = pk + sg.first_packet;                 // (segment-relative indexing: spk[cs + i])
 
   // mode -> (block flag, mapping) from LDS, and — when a thread has few packets — its descriptors loaded up front in one
   // burst and kept in registers for both passes: the kernel is a chain of small dependent loads otherwise, and while it
@@ -141,16 +163,21 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   const bool keep = per <= KEEP;  // then pass B reuses what pass A loaded
   vsyn_packet kq[KEEP];
   const uint32_t num_modes = H->num_modes, bs0 = H->bs[0], bs1 = H->bs[1];
-  uint32_t carry_prev_mode = 0xFFFFFFFFu;  // mode of packet qb-1 (for the block size before this thread's first packet)
-  if (qb > 0 && qb < num) carry_prev_mode = spk[qb - 1].mode;
+  uint32_t carry_prev_mode = 0xFFFFFFFFu;  // mode of the packet before this thread's first one (for the block size in front of it)
+  if (cs + qb > 0 && qb < cn) carry_prev_mode = spk[cs + qb - 1].mode;
   __syncthreads();
   auto n_of_mode = [&](uint32_t m) -> uint32_t { return (m < num_modes && s_bf[m]) ? bs1 : bs0; };
+  if (t == 0 && cs > 0) {  // the halo bit of the chunk's first run
+    const uint32_t m = spk[cs - 1].mode;
+    if (m < num_modes && s_bf[m]) atomicOr(&s_longbits[0], 1u);
+  }
+  const uint32_t prev_n0 = cs + qb == 0 ? carry_n : (qb < cn ? n_of_mode(carry_prev_mode) : 0);
 
   // pass A: per-thread aggregate
   AbsScan agg = {0, 0};
   uint64_t res = 0;
   {
-    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? n_of_mode(carry_prev_mode) : 0);
+    uint32_t prev_n = prev_n0;
     auto step_a = [&](const vsyn_packet& k) {
       const uint32_t n = n_of_mode(k.mode);
       AbsScan e;
@@ -160,21 +187,21 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       res += (uint64_t)C * (n / 2);
       prev_n = n;
     };
-    // KEEP descriptors per burst: one exposed round trip per burst instead of one per packet (long segments: 16 x 4096 packets
-    // 204 -> 224 M packets/s; a 1024-thread block, which would hold any segment in one burst, measured WORSE — 191 M — because a
-    // block that wide cannot sit next to a synthesis workgroup at all)
+    // KEEP descriptors per burst: one exposed round trip per burst instead of one per packet
     for (uint32_t base = qb; base < qe; base += KEEP) {
 #pragma unroll
       for (uint32_t j = 0; j < KEEP; ++j)
-        if (base + j < qe) kq[j] = spk[base + j];
+        if (base + j < qe) kq[j] = spk[cs + base + j];
 #pragma unroll
       for (uint32_t j = 0; j < KEEP; ++j)
         if (base + j < qe) step_a(kq[j]);
     }
   }
   // exclusive scan over the thread aggregates: wave-level shuffles, then the wave totals through LDS
+  AbsScan chunk_agg;
+  uint64_t chunk_res;
   {
-    const uint32_t lane = t & 63u, wv = t >> 6;
+    const uint32_t lane = t & 63u, wv = t >> 6, NW = NT >> 6;
     AbsScan inc = agg;
     uint64_t rinc = res;
 #pragma unroll
@@ -199,6 +226,12 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       pre = abs_combine(pre, s_abs[w]);
       rpre += s_res[w];
     }
+    chunk_agg = pre;
+    chunk_res = rpre;
+    for (uint32_t w = wv; w < NW; ++w) {  // (every thread: the chunk's total)
+      chunk_agg = abs_combine(chunk_agg, s_abs[w]);
+      chunk_res += s_res[w];
+    }
     // exclusive = (prefix of earlier waves) o (inclusive of lane-1)
     AbsScan ex;
     ex.val = __shfl_up(inc.val, 1);
@@ -215,15 +248,60 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     s_abs[t] = ex;
     s_res[t] = rex;
   }
+  // chunk chain (segments longer than one chunk only): decoupled look-back over the predecessors' records
+  if (chunks_per_seg > 1) {
+    if (t == 0) {
+      LayoutChunk* mine = chunks + (size_t)g * chunks_per_seg + ch;
+      AbsScan ex = {0, 0};
+      uint64_t rex = 0;
+      if (ch > 0) {
+        mine->agg_val = chunk_agg.val;
+        mine->agg_set = (uint32_t)chunk_agg.set;
+        mine->agg_res = chunk_res;
+        __hip_atomic_store(&mine->flag, epoch * 4u + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        AbsScan run = {0, 0};  // aggregate of the chunks between the record in hand and this chunk
+        uint64_t rrun = 0;
+        for (uint32_t pc = ch; pc-- > 0;) {
+          LayoutChunk* pr = chunks + (size_t)g * chunks_per_seg + pc;
+          uint32_t f;
+          uint32_t spins = 0;
+          while (((f = __hip_atomic_load(&pr->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 2) != epoch || (f & 3u) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 24)) break;  // (bounded: a predecessor that never arrives cannot hang the device)
+          }
+          if ((f & 3u) == 2u) {
+            AbsScan a = {pr->inc_val, (int)pr->inc_set};
+            ex = abs_combine(a, run);
+            rex = pr->inc_res + rrun;
+            break;
+          }
+          AbsScan a = {pr->agg_val, (int)pr->agg_set};
+          run = abs_combine(a, run);
+          rrun += pr->agg_res;
+        }
+      }
+      const AbsScan incl = abs_combine(ex, chunk_agg);
+      mine->inc_val = incl.val;
+      mine->inc_set = (uint32_t)incl.set;
+      mine->inc_res = rex + chunk_res;
+      __hip_atomic_store(&mine->flag, epoch * 4u + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_chunk_ex = ex;
+      s_chunk_rex = rex;
+    }
+  } else if (t == 0) {
+    s_chunk_ex = AbsScan{0, 0};
+    s_chunk_rex = 0;
+  }
   __syncthreads();
 
   // pass B
   {
-    AbsScan pre = s_abs[t];
+    AbsScan pre = abs_combine(s_chunk_ex, s_abs[t]);
     int64_t abs_before = pre.set ? pre.val : abs0 + pre.val;
-    uint64_t res_off = sg.residue_off + s_res[t];
-    uint32_t prev_n = qb == 0 ? carry_n : (qb < num ? n_of_mode(carry_prev_mode) : 0);
-    auto step_b = [&](uint32_t q, const vsyn_packet& k) {
+    uint64_t res_off = sg.residue_off + s_chunk_rex + s_res[t];
+    uint32_t prev_n = prev_n0;
+    auto step_b = [&](uint32_t ql, const vsyn_packet& k) {  // ql: index inside the chunk
+      const uint32_t q = cs + ql;
       const uint32_t p = sg.first_packet + q;
       PktInfo pi = {};
       const bool mode_ok = k.mode < num_modes;
@@ -269,7 +347,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       pi.own = own;
       pi.used = used;
       info[p] = pi;
-      if (use_bits && mode_ok && lng) atomicOr(&s_longbits[q >> 5], 1u << (q & 31u));
+      if (mode_ok && lng) atomicOr(&s_longbits[(ql + 1u) >> 5], 1u << ((ql + 1u) & 31u));
       seg_of_pkt[p] = g;
       if (emit_len) emit_len[p] = emit;
       if (q == num - 1) {
@@ -284,7 +362,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       if (!keep) {
 #pragma unroll
         for (uint32_t j = 0; j < KEEP; ++j)
-          if (base + j < qe) kq[j] = spk[base + j];
+          if (base + j < qe) kq[j] = spk[cs + base + j];
       }
 #pragma unroll
       for (uint32_t j = 0; j < KEEP; ++j)
@@ -293,16 +371,16 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   }
   __syncthreads();
 
-  // pass C: classify runs of R packets. A run goes to the fused long-block kernel iff every packet it touches
+  // pass C: classify the chunk's runs of R packets. A run goes to the fused long-block kernel iff every packet it touches
   // (its one-packet halo included) is a valid long block and any carry-in is a long block; all other runs are
   // appended to the staged work list (entry = packet index | emit << 31; halo packets carry emit = 0).
   {
     const uint32_t nruns = (num + R - 1) / R;
-    for (uint32_t r = t; r < runs_per_seg; r += NT) {
+    for (uint32_t r = ch * runs_per_chunk + t; r < min(runs_per_seg, (ch + 1u) * runs_per_chunk); r += NT) {
       const uint32_t qa = r * R, qb2 = min(num, qa + R);
+      // (bitmap positions: packet q of the chunk at bit q - cs + 1; the halo of the chunk's first run at bit 0)
       const uint32_t cls = r >= nruns ? 0xFFu  // 0xFF: no such run
-                           : use_bits ? run_class_bits(s_longbits, qa, qb2, carry_n, fused_ok)
-                                      : run_class(H, spk, qa, qb2, carry_n, fused_ok);
+                                      : run_class_bits(s_longbits, qa - cs + 1u, qb2 - cs + 1u, qa == 0 ? carry_n : 0u, fused_ok, qa == 0);
       run_cls[(size_t)g * runs_per_seg + r] = (uint8_t)cls;  // the fused kernels read this instead of re-deriving it
       if (r >= nruns || cls) continue;
       const bool prev_fast = qa > 0 && run_class(H, spk, qa - R, qa, carry_n, fused_ok) != 0;
@@ -312,7 +390,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
       for (uint32_t q = qa; q < qb2; ++q) staged_list[at++] = (sg.first_packet + q) | 0x80000000u;
     }
   }
-  if (t == 0) {
+  if (t == 0 && (last_chunk || num == 0)) {
     SegInfo si;
     si.has_carry = carry_n ? 1u : 0u;
     si.carry_n = carry_n;
