@@ -31,8 +31,18 @@ struct ULdsSize {           // one block size; every table in exactly the order 
                             // for next-flag f is its mirror. Short blocks: both flags hold the one short window
 };
 struct ULdsImage {
-  ULdsSize sz[2];           // [0] blocksize0, [1] blocksize1
+  ULdsSize sz[2];           // [0] blocksize0, [1] blocksize1 (blocksize1 > 2048: the tables of a 512-point FFT, see UBig)
   float invdb[260];         // Vorbis I 10.1; [255] = 1.0f, [256] = 0.0f as in FusedLdsImage
+};
+// Long blocks of 4096 / 8192 samples (NS = 2 / 4): Np = 512 NS points, NS register sets of 8 per lane; point k = 512 u + 64 t + lane.
+// One radix-NS stage across the sets (twiddle W_Np^((64 t + lane) u')), then NS FFT-512 through the usual network; bin
+// f = u' + NS (kappa + 64 c') ends up in set u', register c'. Follows ULdsImage in LDS.
+template <int NS>
+struct UBig {
+  float2 pre[NS][8][64];
+  float2 post[NS][8][64];
+  float2 tw0[NS][8][64];        // row 0 unused
+  float win[2][2][NS][8][64];   // [window flag][0: at s, 1: at M-1-s][u'][c'][lane]
 };
 
 // per-wave LDS block (dynamic): exchange image | floor entries | packet info of the pass | hand-off flags | carry image
@@ -110,7 +120,7 @@ struct UPass {
   bool valid, after_bad;  // after_bad: an invalid packet was skipped in front of this pass (the overlap chain restarts)
 };
 
-template <int ROLE>
+template <int ROLE, int UNS>
 __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, uint8_t* wmem, const uint8_t* pmem, const uint32_t wave_bytes, const uint32_t lane,
                                       const uint32_t g, const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C,
                                       const uint32_t c) {
@@ -189,7 +199,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
     ps.lng = __builtin_amdgcn_readfirstlane(lng_l);
     ps.map = __builtin_amdgcn_readfirstlane(map_l);
     ps.LG = ps.lng ? lgp[1] : lgp[0];
-    const uint32_t J = min(U_MAX_J, 512u >> ps.LG);
+    const uint32_t J = max(1u, min(U_MAX_J, 512u >> ps.LG));
     const uint64_t okm = __ballot(cand && !bad_l && lng_l == ps.lng && map_l == ps.map && lane < J);
     ps.Jp = (uint32_t)__builtin_ctzll(~okm);  // >= 1
     // {res_off lo, hi, out_pos, emit (0 for the halo), used, own, widx, -}
@@ -248,7 +258,12 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
   if (A.ys) wave_unwrap(A, xb, lane, sg, q0, qb, C, c);
   fetch_info(q0);
   vmem_drain();
-  uint32_t it = 0, qnext = q0, steps_done = 0, coupled_passes = 0;
+  uint32_t it = 0, ep = 0, qnext = q0, steps_done = 0, coupled_passes = 0;  // ep: hand-off rounds so far (the pairwise counters)
+  float PB[UNS > 1 ? UNS : 1][8];  // blocks above 2048: unwindowed right-half values of the previous such block
+#pragma unroll
+  for (int u = 0; u < (UNS > 1 ? UNS : 1); ++u)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) PB[u][k] = 0.f;
   for (;;) {
     // (Forming the NEXT pass early and requesting its residue a pass ahead was measured: 24 more live registers, no gain at the 8-12
     // waves per CU this kernel runs at — 0.221 vs 0.218 ms per 65 536 n = 1024 packets without spills, slower with them.)
@@ -261,6 +276,305 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
       prev_kind = K_REG;
     }
     if ((int)floor_of_pass(cur) != cur_floor || (2u << cur.LG) != cur_floor_M) floor_update(floor_of_pass(cur), 2u << cur.LG);
+    if (UNS > 1 && cur.LG > 9u) {
+      // ============ one block of 4096 / 8192 samples: NS register sets ============================================================
+      constexpr int NS = UNS > 1 ? UNS : 2;
+      const UBig<NS>& B = *(const UBig<NS>*)((const uint8_t*)&T + ((sizeof(ULdsImage) + 15u) & ~15u));
+      const ULdsSize& F = T.sz[1];  // tw1 / tw2 of the 512-point FFT
+      ++it;
+      const uint32_t Npb = 512u * NS, Mb = 2u * Npb, qn = cur.qn;
+      const uint32_t p = sg.first_packet + cur.q;
+      const lds_u32* const pinf = pinf_base;
+      const uint64_t roff = ((uint64_t)pinf[1] << 32) | pinf[0];
+      const uint32_t kap = ((lane & 7u) << 3) | (lane >> 3);
+      // ---- loads ----
+      float2 rb[NS][8];
+      {
+        const float2* src = (const float2*)(A.residue + roff + (size_t)c * Mb) + lane;
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) rb[u][t] = src[512 * u + 64 * t];
+      }
+      uint32_t v = (A.fy + ((size_t)p * C + c) * ys_stride)[sidx];
+      // ---- inverse coupling, one register set per hand-off round ----
+      if (ROLE == 3) {
+        uint8_t* const g0 = wmem - (size_t)c * wave_bytes;
+        lds_u32* const gfl = (lds_u32*)(g0 + U_FLAG_OFF);
+        const MapConst* mc = maps + cur.map;
+        const uint32_t ncoup = __builtin_amdgcn_readfirstlane(mc->ncoup);
+        if (ncoup) {
+#pragma unroll
+          for (int u = 0; u < NS; ++u) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = rb[u][t];
+            ++coupled_passes;
+            if (lane == 0) __atomic_fetch_add(gfl + 2, 1u, __ATOMIC_RELAXED);
+            for (uint32_t i = 0; i < ncoup; ++i) {
+              const uint32_t k = ncoup - 1u - i;
+              const uint32_t cm = __builtin_amdgcn_readfirstlane((uint32_t)mc->coup[2 * k]), ca = __builtin_amdgcn_readfirstlane((uint32_t)mc->coup[2 * k + 1]);
+              if (c == cm) {
+                group_wait(gfl + 2, C * coupled_passes, A.status);
+                group_wait(gfl + 3, steps_done + i, A.status);
+                float2* im = (float2*)(g0 + (size_t)cm * wave_bytes);
+                float2* ia = (float2*)(g0 + (size_t)ca * wave_bytes);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                  float2 vm = im[t * 64 + lane], va = ia[t * 64 + lane];
+                  inverse_couple(vm.x, va.x);
+                  inverse_couple(vm.y, va.y);
+                  im[t * 64 + lane] = vm;
+                  ia[t * 64 + lane] = va;
+                }
+                pair_post(gfl + 3, steps_done + i + 1u);
+              }
+            }
+            group_wait(gfl + 3, steps_done + ncoup, A.status);
+            steps_done += ncoup;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rb[u][t] = xb[t * 64 + lane];
+          }
+        }
+      } else if (ROLE != 0) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = rb[u][t];
+          ++ep;
+          pair_post(&my_flags[0], ep);
+          pair_wait(&partner_flags[0], ep);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float2 oth = pxb[t * 64 + lane];
+            rb[u][t] = ROLE == 1 ? f2(couple_mag(rb[u][t].x, oth.x), couple_mag(rb[u][t].y, oth.y))
+                                 : f2(couple_ang(oth.x, rb[u][t].x), couple_ang(oth.y, rb[u][t].y));
+          }
+          pair_post(&my_flags[1], ep);
+          pair_wait(&partner_flags[1], ep);
+        }
+      }
+      // ---- floor curve + product (hpp:563-589, 1243-1255): table per sorted-post interval, bins of this lane looked up directly ----
+      bool floor_bad = false;
+      {
+        const uint32_t own_b = pinf[5], used_b = pinf[4];
+        const bool nocurve = !((own_b >> c) & 1u);
+        if (nocurve) {
+          seg2[lane] = f2(0.f, ((used_b >> c) & 1u) ? 256.5f : 255.5f);
+        } else {
+          if (lane >= posts) v = 0;
+          const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
+          const uint64_t below = mask & ((2ull << lane) - 1ull);
+          const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
+          const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
+          const bool has_hi = above != 0ull;
+          const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
+          const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
+          const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
+          const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
+          floor_bad = (v & 0x7FFFu) > 255u;
+          const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
+          const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
+          const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
+          const float ady = fabsf(y1 - y0);
+          const float a = ady * inv, b = __builtin_fmaf(-ady, x0, 0.5f) * inv;
+          seg2[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);
+        }
+        const uint8_t* bs = A.binseg + (size_t)cur_floor * half1;
+        const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2;
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const uint32_t k = 512u * u + 64u * t + lane;
+            const uint32_t two = nocurve ? 0u : (uint32_t) * (const uint16_t*)(bs + 2u * k);
+            const u_f32x2 e0 = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * (two & 0xFFu));
+            const u_f32x2 e1 = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * (two >> 8));
+            const uint32_t i0 = (uint32_t)__builtin_fmaf((float)(2u * k), e0.x, e0.y), i1 = (uint32_t)__builtin_fmaf((float)(2u * k + 1u), e1.x, e1.y);
+            rb[u][t] = f2(rb[u][t].x * T.invdb[i0], rb[u][t].y * T.invdb[i1]);
+          }
+      }
+      // ---- IMDCT: mirror element (set NS-1-u, register 7-t, lane 63-l), pre-rotation, radix-NS across the sets, NS x FFT-512 ----
+      float2 zb[NS][8];
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) zb[u][t] = cmulf(f2(rb[u][t].x, __shfl(rb[NS - 1 - u][7 - t].y, 63 - (int)lane)), B.pre[u][t][lane]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (NS == 2) {
+          const float2 a = cadd(zb[0][t], zb[1][t]), d = csub(zb[0][t], zb[1][t]);
+          zb[0][t] = a;
+          zb[1][t] = d;
+        } else {
+          u_dft4(zb[0][t], zb[1][t], zb[2 % NS][t], zb[3 % NS][t]);
+        }
+#pragma unroll
+        for (int u = 1; u < NS; ++u) zb[u][t] = cmulf(zb[u][t], B.tw0[u][t][lane]);
+      }
+      {
+        const uint32_t cl = lane & 7u, hi = lane >> 3;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          float2(&z)[8] = zb[u];
+          dft8(z);
+#pragma unroll
+          for (int t = 1; t < 8; ++t) z[t] = cmulf(z[t], F.tw1[t][lane]);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) xb[t * 72 + lane] = z[t];
+#pragma unroll
+          for (int a = 0; a < 8; ++a) z[a] = xb[hi * 72 + a * 8 + cl];
+          dft8(z);
+#pragma unroll
+          for (int a = 1; a < 8; ++a) z[a] = cmulf(z[a], F.tw2[a][cl]);
+#pragma unroll
+          for (int a = 0; a < 8; ++a) xb[a * 65 + lane] = z[a];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) z[k] = xb[cl * 65 + hi * 8 + k];
+          dft8(z);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], B.post[u][k][lane]);
+        }
+      }
+      // ---- window + overlap-add + PCM: bin f = u' + NS (kappa + 64 c'); s = 2f - Np (c' >= 4) resp. Np - 1 - 2f ----
+      const uint32_t emit = pinf[3], widx_b = pinf[6];
+      float* const out = plane + pinf[2];
+      const uint32_t shift = (prev_M && prev_M != Mb) ? (uint32_t)(((int32_t)prev_M - (int32_t)Mb) / 2) : 0u;
+      const uint32_t fL = widx_b & 1u, fR = prev_next_long;
+      if (prev_kind == K_CARRY && prev_M != Mb) {  // carry-in of a smaller block (a larger one does not exist): into the carry image
+        for (uint32_t i = lane; i < prev_M; i += 64) cbuf[i] = cin[i];
+        prev_kind = K_LDS;
+      }
+      const bool last_of_segment = qn == num;
+      uint32_t next_M = 0, next_emit = 0, next_out = 0;
+      vmem_drain();
+      if (qn < qb) {
+        const uint32_t nbad = __builtin_amdgcn_readfirstlane((nfb[3] >> 8) & 0xFFu), nlng = __builtin_amdgcn_readfirstlane((nfb[2] >> 16) & 0xFFu);
+        next_M = nbad ? 0u : (2u << (nlng ? lgp[1] : lgp[0]));
+        next_emit = __builtin_amdgcn_readfirstlane(qn < qa ? 0u : nfa[3]);
+        next_out = __builtin_amdgcn_readfirstlane(nfa[2]);
+      }
+      const bool hand_over = next_M && next_M != Mb;
+      const uint32_t cur_next_long = (widx_b >> 1) & 1u;
+      const bool whole = emit == Mb + shift && (int)shift >= 0 && (((uintptr_t)out & 15u) == 0);
+      float os[NS][4], om[NS][4], ns_[NS][4], nm_[NS][4];
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        float wl0[8], wl1[8], wr0[8], wr1[8], Pin[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          wl0[k] = B.win[fL][0][u][k][lane];
+          wl1[k] = B.win[fL][1][u][k][lane];
+          wr0[k] = B.win[fR][0][u][k][lane];
+          wr1[k] = B.win[fR][1][u][k][lane];
+          Pin[k] = PB[u][k];
+        }
+        if (prev_kind != K_REG) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t f = u + NS * (kap + 64u * k);
+            const uint32_t s0 = k >= 4 ? 2u * f - Npb : Npb - 1u - 2u * f;
+            float vs, vm;
+            if (prev_kind == K_CARRY) {
+              vs = cin[s0];
+              vm = cin[Mb - 1u - s0];
+            } else {  // after a smaller block: its prev_M windowed samples meet this block's samples [D, D + prev_M)
+              const uint32_t D = (Mb - prev_M) / 2u;
+              const bool in = s0 >= D && s0 < D + prev_M;
+              vs = in ? cbuf[s0 - D] : 0.f;
+              vm = in ? cbuf[Mb - 1u - s0 - D] : 0.f;
+            }
+            Pin[k] = 1.f;
+            wr1[k] = vs;
+            wr0[k] = vm;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kh = 4 + j, kl = 3 - j;
+          const float cch = zb[u][kh].x, ccl = -zb[u][kl].y;
+          const float ah_s = Pin[kh] * wr1[kh], ah_m = Pin[kh] * wr0[kh], al_s = Pin[kl] * wr1[kl], al_m = Pin[kl] * wr0[kl];
+          os[u][j] = ah_s + cch * wl0[kh];
+          om[u][j] = ah_m + (-cch) * wl1[kh];
+          // the odd neighbours of set NS-1-u's even samples: exchanged with the mirror lane below
+          ns_[u][j] = al_s + ccl * wl0[kl];
+          nm_[u][j] = al_m + (-ccl) * wl1[kl];
+        }
+        if ((last_of_segment || hand_over)) {
+          float* cout = A.carry + (si.parity_in ^ 1u) * carry_half + ((size_t)sg.stream * C + c) * half1;
+          float* nxtp = plane + next_out;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t f = u + NS * (kap + 64u * k);
+            const uint32_t s0 = k >= 4 ? 2u * f - Npb : Npb - 1u - 2u * f, sm = Mb - 1u - s0;
+            const float pn = k >= 4 ? zb[u][k].y : -zb[u][k].x;
+            const float v_s = pn * B.win[cur_next_long][1][u][k][lane], v_m = pn * B.win[cur_next_long][0][u][k][lane];
+            if (last_of_segment) {
+              cout[s0] = v_s;
+              cout[sm] = v_m;
+            } else {  // a smaller block follows
+              const uint32_t D = (Mb - next_M) / 2u;
+              if (s0 < D) {
+                if (s0 < next_emit) nxtp[s0] = v_s;
+              } else if (s0 < D + next_M) {
+                cbuf[s0 - D] = v_s;
+              }
+              if (sm < D) {
+                if (sm < next_emit) nxtp[sm] = v_m;
+              } else if (sm < D + next_M) {
+                cbuf[sm - D] = v_m;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) PB[u][k] = k >= 4 ? zb[u][k].y : -zb[u][k].x;
+      }
+      // the sample next to (set u, c' = 4 + j)'s even sample s comes from (set NS-1-u, c' = 3 - j) of the mirror lane
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = __shfl(ns_[u][j], 63 - (int)lane), b = __shfl(nm_[u][j], 63 - (int)lane);
+          ns_[u][j] = a;
+          nm_[u][j] = b;
+        }
+      // set u, c' = 4 + j: s = 2u + 2 NS kappa + 128 NS j; a lane's NS sets give 2 NS consecutive samples (and 2 NS descending ones)
+      if (whole) {
+        float* up = out + shift + 2u * NS * kap;
+        float* dn = out + shift + Mb - 2u * NS - 2u * NS * kap;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int h = 0; h < NS / 2; ++h) {
+            *(float4*)(up + 128 * NS * j + 4 * h) = make_float4(os[2 * h][j], ns_[NS - 1 - 2 * h][j], os[2 * h + 1][j], ns_[NS - 2 - 2 * h][j]);
+            *(float4*)(dn - 128 * NS * j + 4 * h) =
+                make_float4(nm_[2 * h][j], om[NS - 1 - 2 * h][j], nm_[2 * h + 1][j], om[NS - 2 - 2 * h][j]);
+          }
+        }
+      } else if (emit) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t s0 = 2u * u + 2u * NS * kap + 128u * NS * j;
+            const uint32_t f0 = s0 + shift, f1 = s0 + 1u + shift, f2m = Mb - 2u - s0 + shift, f3m = Mb - 1u - s0 + shift;
+            if (f0 < emit) out[f0] = os[u][j];
+            if (f1 < emit) out[f1] = ns_[NS - 1 - u][j];
+            if (f2m < emit) out[f2m] = nm_[NS - 1 - u][j];
+            if (f3m < emit) out[f3m] = om[u][j];
+          }
+      }
+      if (__any(floor_bad)) {
+        if (lane == 0) raise_status(A.status, VSYN_ST_FLOOR_VALUE, p);
+        vmem_drain();
+      }
+      prev_kind = hand_over ? K_LDS : K_REG;
+      prev_M = Mb;
+      prev_next_long = cur_next_long;
+      qnext = qn;
+      if (qnext >= qb) break;
+      continue;
+    }
     load_residue(cur);
     load_rows(cur);
     ++it;
@@ -315,14 +629,15 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
     } else if (ROLE != 0) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
-      pair_post(&my_flags[0], it);
-      pair_wait(&partner_flags[0], it);
+      ++ep;
+      pair_post(&my_flags[0], ep);
+      pair_wait(&partner_flags[0], ep);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const float2 oth = pxb[t * 64 + lane];
         r[t] = ROLE == 1 ? f2(couple_mag(raw[t].x, oth.x), couple_mag(raw[t].y, oth.y)) : f2(couple_ang(oth.x, raw[t].x), couple_ang(oth.y, raw[t].y));
       }
-      pair_post(&my_flags[1], it);
+      pair_post(&my_flags[1], ep);
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) r[t] = raw[t];
@@ -334,7 +649,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 #pragma unroll
     for (uint32_t j = 0; j < U_MAX_J / 2; ++j) vcur[j] = (vrow[2 * j] & 0xFFFFu) | (vrow[2 * j + 1] << 16);
 
-    if (ROLE == 1 || ROLE == 2) pair_wait(&partner_flags[1], it);  // the partner has read this wave's image: it may be reused (floor factors, FFT)
+    if (ROLE == 1 || ROLE == 2) pair_wait(&partner_flags[1], ep);  // the partner has read this wave's image: it may be reused (floor factors, FFT)
 
     // ---- floor curve, packet by packet, in bin order (hpp:563-589) -----------------------------------------------------------------
     bool floor_bad = false;
@@ -641,7 +956,8 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 
 // grid: groups of WPB = blockDim.x / 64 units (segment, run, channel), flattened as in vsyn_fused_kernel; the channels of a run are
 // adjacent waves of one workgroup. Takes every run of class 2 (with the tuned long-run kernel absent: every run).
-__global__ void __launch_bounds__(U_MAX_THREADS) vsyn_fused_u_kernel(const UArgs U) {
+template <int UNS>
+__global__ void __launch_bounds__(UNS == 1 ? U_MAX_THREADS : 512) vsyn_fused_u_kernel(const UArgs U) {
   extern __shared__ __attribute__((aligned(16))) uint8_t u_lds[];
   const FusedArgs& A = U.f;
   const ConstHeader* H = hdr_of(A.cb);
@@ -670,7 +986,7 @@ __global__ void __launch_bounds__(U_MAX_THREADS) vsyn_fused_u_kernel(const UArgs
   {
     const uint4* src = (const uint4*)U.img;
     uint4* dst = (uint4*)u_lds;
-    for (uint32_t i = threadIdx.x; i < sizeof(ULdsImage) / 16; i += blockDim.x) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < U.table_bytes / 16; i += blockDim.x) dst[i] = src[i];
   }
   uint8_t* wmem = u_lds + U.table_bytes + wave * U.wave_bytes;
   if (lane < 4) ((uint32_t*)(wmem + U_FLAG_OFF))[lane] = 0u;
@@ -681,10 +997,10 @@ __global__ void __launch_bounds__(U_MAX_THREADS) vsyn_fused_u_kernel(const UArgs
   const int role = U.role_mode == 3 ? 3 : ((U.role_mode == 0 || C < 2) ? 0 : (c == mag ? 1 : 2));
   const uint32_t pw = (role == 1 || role == 2) ? (wave ^ 1u) : wave;
   const uint8_t* pmem = u_lds + U.table_bytes + pw * U.wave_bytes;
-  if (role == 0) u_run<0>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
-  else if (role == 1) u_run<1>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
-  else if (role == 2) u_run<2>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
-  else u_run<3>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  if (role == 0) u_run<0, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else if (role == 1) u_run<1, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else if (role == 2) u_run<2, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else u_run<3, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -692,11 +1008,12 @@ __global__ void __launch_bounds__(U_MAX_THREADS) vsyn_fused_u_kernel(const UArgs
 // ------------------------------------------------------------------------------------------------
 struct UTables {
   ULdsImage* d_img = nullptr;
-  uint32_t wave_bytes = 0, table_bytes = 0, waves_per_block = 0, waves_per_cu = 0, role_mode = 0;
+  uint32_t wave_bytes = 0, table_bytes = 0, waves_per_block = 0, waves_per_cu = 0, role_mode = 0, ns = 1;
 };
 
 static inline bool u_supported(const ConstHeader& H, const uint8_t* host_const) {
-  if (H.bs[1] > 2048 || H.channels > U_MAX_CH) return false;
+  // blocksize1 up to 8192 (register sets, UBig); blocksize0 must fit the packed passes
+  if (H.bs[0] > 2048 || H.channels > U_MAX_CH) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
   for (uint32_t f = 0; f < H.num_floors; ++f)
     if (fl[f].posts > 64) return false;
@@ -755,30 +1072,65 @@ static inline void u_fill_size(const ConstHeader& H, const uint8_t* host_const, 
     }
 }
 
+template <int NS>
+static inline void u_fill_big(const ConstHeader& H, const uint8_t* host_const, ULdsSize& F, UBig<NS>& B) {
+  const uint32_t n = H.bs[1], M = n / 2, Np = n / 4;
+  const float2* pre = (const float2*)(host_const + H.off_pre[1]);
+  const float2* post = (const float2*)(host_const + H.off_post[1]);
+  const float2* tw = (const float2*)(host_const + H.off_fft[1]);  // W_Np^j
+  const float* win = (const float*)(host_const + H.off_win[1]);
+  memset(&F, 0, sizeof(F));
+  for (uint32_t l = 0; l < 64; ++l) {
+    const uint32_t kappa = ((l & 7) << 3) | (l >> 3);
+    for (uint32_t t = 0; t < 8; ++t) {
+      F.tw1[t][l] = tw[((l * t) & 511u) * NS];  // W512^(l t)
+      for (uint32_t u = 0; u < (uint32_t)NS; ++u) {
+        B.pre[u][t][l] = pre[512 * u + 64 * t + l];
+        B.tw0[u][t][l] = tw[((64 * t + l) * u) & (Np - 1)];
+        const uint32_t f = u + NS * (kappa + 64 * t);  // t plays c' here
+        B.post[u][t][l] = post[f];
+        const uint32_t s = t >= 4 ? 2 * f - Np : Np - 1 - 2 * f;
+        for (uint32_t fl = 0; fl < 2; ++fl) {
+          B.win[fl][0][u][t][l] = win[(size_t)fl * n + s];
+          B.win[fl][1][u][t][l] = win[(size_t)fl * n + (M - 1 - s)];
+        }
+      }
+    }
+  }
+  for (uint32_t a = 0; a < 8; ++a)
+    for (uint32_t c = 0; c < 8; ++c) F.tw2[a][c] = tw[((8 * c * a) & 511u) * NS];  // W64^(c a)
+}
+
 static inline hipError_t u_tables_create(const ConstHeader& H, const uint8_t* host_const, UTables* ut) {
-  std::vector<ULdsImage> v(1);
-  memset(&v[0], 0, sizeof(ULdsImage));
-  u_fill_size(H, host_const, 0, v[0].sz[0]);
-  u_fill_size(H, host_const, 1, v[0].sz[1]);
-  memcpy(v[0].invdb, host_const + H.off_invdb, 256 * sizeof(float));
-  hipError_t e = hipMalloc((void**)&ut->d_img, sizeof(ULdsImage));
+  const uint32_t ns = H.bs[1] > 2048 ? H.bs[1] / 2048 : 1;
+  const uint32_t img_bytes = (uint32_t)((sizeof(ULdsImage) + 15u) & ~15u);
+  const uint32_t big_bytes = ns == 2 ? (uint32_t)sizeof(UBig<2>) : (ns == 4 ? (uint32_t)sizeof(UBig<4>) : 0u);
+  std::vector<uint8_t> blob(img_bytes + big_bytes, 0);
+  ULdsImage& im = *(ULdsImage*)blob.data();
+  u_fill_size(H, host_const, 0, im.sz[0]);
+  if (ns == 1) u_fill_size(H, host_const, 1, im.sz[1]);
+  else if (ns == 2) u_fill_big<2>(H, host_const, im.sz[1], *(UBig<2>*)(blob.data() + img_bytes));
+  else u_fill_big<4>(H, host_const, im.sz[1], *(UBig<4>*)(blob.data() + img_bytes));
+  memcpy(im.invdb, host_const + H.off_invdb, 256 * sizeof(float));
+  hipError_t e = hipMalloc((void**)&ut->d_img, blob.size());
   if (e != hipSuccess) return e;
-  e = hipMemcpy(ut->d_img, &v[0], sizeof(ULdsImage), hipMemcpyHostToDevice);
+  e = hipMemcpy(ut->d_img, blob.data(), blob.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) return e;
-  ut->table_bytes = (uint32_t)((sizeof(ULdsImage) + 15u) & ~15u);
+  ut->ns = ns;
+  ut->table_bytes = (uint32_t)blob.size();
   const uint32_t cbuf = H.bs[0] != H.bs[1] ? (H.bs[0] / 2) * 4u : 16u;
   ut->wave_bytes = (U_CBUF_OFF + cbuf + 15u) & ~15u;
   const uint32_t budget = 156u * 1024u;
   uint32_t w = (budget - ut->table_bytes) / ut->wave_bytes;
-  w = std::min<uint32_t>(U_MAX_THREADS / 64u, w);
+  w = std::min<uint32_t>(ns == 1 ? U_MAX_THREADS / 64u : 8u, w);
   ut->role_mode = u_role_mode(H, host_const);
   // the channel waves of a run share a workgroup: a multiple of the channel count (of 2 for the pairwise swap)
   const uint32_t grp = ut->role_mode == 3 ? H.channels : 2u;
   if (w < grp) return hipErrorInvalidValue;
   ut->waves_per_block = w / grp * grp;
   ut->waves_per_cu = ut->waves_per_block;  // one workgroup per CU (the tables take a quarter of the LDS)
-  e = hipFuncSetAttribute((const void*)vsyn_fused_u_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)(ut->table_bytes + ut->waves_per_block * ut->wave_bytes));
+  const void* kfn = ns == 1 ? (const void*)vsyn_fused_u_kernel<1> : (ns == 2 ? (const void*)vsyn_fused_u_kernel<2> : (const void*)vsyn_fused_u_kernel<4>);
+  e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ut->table_bytes + ut->waves_per_block * ut->wave_bytes));
   if (e != hipSuccess && getenv("VSYN_DEBUG"))
     fprintf(stderr, "vsyn: hipFuncSetAttribute(%u B dynamic LDS) failed: %s\n", ut->table_bytes + ut->waves_per_block * ut->wave_bytes, hipGetErrorString(e));
   return e;
@@ -800,6 +1152,9 @@ static inline hipError_t u_launch(const ConstHeader& H, const UTables& ut, const
   u.role_mode = ut.role_mode;
   const uint32_t wpb = ut.waves_per_block;
   dim3 grid((uint32_t)((units + wpb - 1) / wpb));
-  vsyn_fused_u_kernel<<<grid, wpb * 64, ut.table_bytes + wpb * ut.wave_bytes, s>>>(u);
+  const size_t lds = ut.table_bytes + (size_t)wpb * ut.wave_bytes;
+  if (ut.ns == 1) vsyn_fused_u_kernel<1><<<grid, wpb * 64, lds, s>>>(u);
+  else if (ut.ns == 2) vsyn_fused_u_kernel<2><<<grid, wpb * 64, lds, s>>>(u);
+  else vsyn_fused_u_kernel<4><<<grid, wpb * 64, lds, s>>>(u);
   return hipGetLastError();
 }

@@ -92,6 +92,11 @@ SHAPES = [  # (channels, bs0, bs1, pattern, streams, packets)
     (2, 2048, 2048, "long", 2, 12),
     (2, 128, 2048, "mixed", 2, 45),
     (2, 1024, 2048, "mixed", 2, 25),
+    (2, 512, 4096, "mixed", 2, 35),    # blocks above 2048: register sets (UBig)
+    (1, 256, 4096, "mixed", 2, 30),
+    (2, 4096, 4096, "long", 2, 10),
+    (2, 1024, 8192, "mixed", 2, 28),
+    (1, 64, 8192, "mixed", 1, 40),
     (2, 256, 2048, "mixed", 2, 2300),  # segments of several thousand packets: the layout kernel's bursts
     (1, 256, 2048, "mixed", 1, 16500),  # one very long segment: the layout kernel's 1024-thread block
 ]
