@@ -923,6 +923,13 @@ OkOrError VorbisStream::parse_audio(const uint8_t* data, uint32_t len, int64_t g
     if (vq_mode_) CHECK_ERR(res.decode_entries(reader, setup.codebooks, (uint32_t)outs.size(), ch_used, n2, cls_, entries_));
     else CHECK_ERR(res.decode(reader, setup.codebooks, (uint32_t)outs.size(), ch_used, n2, outs.data()));
   }
+  {
+    // fault injection for the tests (tests/test_host_decoder.py): the k-th audio packet of every stream fails HERE, after its floor
+    // rows and residue have been appended — the worst place for the batch bookkeeping (a lookup-type-0 book in a residue, a floor-0
+    // submap or a partition overshoot fail at the same depth, but no fixture holds one)
+    static const long fail_at = getenv("PARSEOGGVORBIS_TEST_FAIL_AT") ? atol(getenv("PARSEOGGVORBIS_TEST_FAIL_AT")) : -1;
+    if (fail_at >= 0 && (long)(packets_seen_++) == fail_at) CHECK(false && "injected failure (PARSEOGGVORBIS_TEST_FAIL_AT)");
+  }
   if (vq_mode_) {
     vqp.num_entries = (uint32_t)(entries_.size() - vqp.entry_off);
     vq_pk_.push_back(vqp);

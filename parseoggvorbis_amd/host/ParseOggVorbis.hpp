@@ -232,6 +232,7 @@ struct VorbisStream {
   std::vector<uint8_t> cls_;
   std::vector<uint16_t> entries_;
   size_t residue_floats_ = 0;
+  uint64_t packets_seen_ = 0;          // audio packets parsed so far (only counted under PARSEOGGVORBIS_TEST_FAIL_AT)
 };
 
 struct OggReader {

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string>
+
 #include "../parseoggvorbis_amd/host/ParseOggVorbis.hpp"
 
 namespace {
@@ -25,7 +27,41 @@ struct Collect : SynthSink {
 };
 }  // namespace
 
+// --check in.ogg: a damaged file may fail in the middle of a packet; whatever batch the reader then hands over (it flushes the
+// complete packets in front of the error) must be self-consistent — every per-packet vector as long as pk says. A packet that
+// failed half way and left its rows behind made CorpusDecoder's feeders copy past their staging buffers (round-1 advisor finding).
+static int check_mode(const char* path) {
+  ParseCallbacks cb;
+  Collect sink;
+  OggReader reader(cb);
+  reader.sink_ = &sink;
+  reader.batch_limit_override_ = 0xffffffffu;
+  const OkOrError r = reader.full_read(path);
+  const PacketBatch& b = sink.batch;
+  const uint32_t C = sink.header.audio_channels;
+  bool ok = true;
+  if (sink.batches) {
+    size_t floats = 0;
+    for (const vsyn_packet& k : b.pk) {
+      (void)k;
+    }
+    ok = ok && b.ys.size() == b.pk.size() * C * sink.ys_stride && b.floor_number.size() == b.pk.size() * C;
+    if (b.vq) {
+      ok = ok && b.vq_pk.size() == b.pk.size() && b.residue.empty();
+      if (!b.vq_pk.empty()) ok = ok && b.vq_pk.back().entry_off + b.vq_pk.back().num_entries == b.entries.size() && b.vq_pk.back().cls_off <= b.cls.size();
+      else ok = ok && b.entries.empty() && b.cls.empty();
+    } else {
+      ok = ok && b.residue.size() == b.residue_floats;
+    }
+    (void)floats;
+  }
+  printf("%s batches=%u packets=%zu error=%d %s\n", ok ? "consistent" : "INCONSISTENT", sink.batches, b.pk.size(), r.is_error_ ? 1 : 0,
+         r.is_error_ ? r.err_msg_.c_str() : "");
+  return ok ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 3 && std::string(argv[1]) == "--check") return check_mode(argv[2]);
   if (argc != 3) return 2;
   ParseCallbacks cb;
   Collect sink;

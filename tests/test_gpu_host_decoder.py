@@ -308,3 +308,24 @@ def test_corpus_decoder_int16_output():
         assert ok16[i] and fr[i] == frames[i], names[i]
         want = ob.pcm_interleave(1, np.ascontiguousarray(pcm[i][:, :frames[i]]), frames[i])
         assert np.array_equal(out[i][:frames[i]], want), names[i]
+
+
+@pytest.mark.parametrize("vq", ["1", "0"])
+def test_error_in_mid_stream_still_delivers_the_packets_before_it(vq, tmp_path):
+    """The reference hands PCM out packet by packet, so when a CHECK fires in packet k the hooks and gotPcmData have seen everything
+    before it (hpp:1045-1054). Here those packets sit in a batch: the reader synthesises and delivers them, then reports the error
+    (fault injection: the 20th audio packet fails half way, after its floor rows and residue were appended)."""
+    name, k = "test.stereo44khz", 20
+    spec, b, z = load_golden(name)
+    dump = str(tmp_path / "d.bin")
+    env = dict(os.environ, PARSEOGGVORBIS_TEST_FAIL_AT=str(k), PARSEOGGVORBIS_VQ=vq)
+    r = subprocess.run([CLI, "--in", os.path.join(GOLDEN, name + ".ogg"), "--debug_out", dump], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "injected failure" in (r.stdout + r.stderr)
+    header, entries = read_dump(dump)
+    setup, packets, pcm = split_packets(entries, spec.channels)
+    assert len(packets) == k
+    want = int(b["emit_len"][:k].sum())
+    for c in range(spec.channels):
+        got = np.concatenate(pcm[c]) if len(pcm[c]) else np.zeros(0, np.float32)
+        assert got.shape[0] == want
+        assert np.abs(got - b["pcm"][c, :want]).max() < TOL

@@ -245,6 +245,60 @@ def test_mutated_files_never_crash_the_front_end(built, tmp_path):
     assert out["files"] == 48 and 0 < out["failed"] <= 48
 
 
+@pytest.mark.parametrize("vq", ["1", "0"])
+def test_packet_that_fails_half_way_leaves_the_batch_consistent(probe, tmp_path, vq):
+    """Damage INSIDE audio packets (page CRCs re-computed): the entropy half may give up in the middle of a packet, after it has
+    appended floor rows / residue / entry numbers. The batch it then hands over (the reader delivers the good packets in front of
+    the error, as the reference does packet by packet, hpp:1045-1054) must account for every row: ys, floor numbers, residue or
+    entries exactly as long as the packet list says. (CorpusDecoder's feeders size their staging buffers from the packet list.)"""
+    tab = []
+    for i in range(256):
+        r = i << 24
+        for _ in range(8):
+            r = ((r << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if r & 0x80000000 else (r << 1) & 0xFFFFFFFF
+        tab.append(r)
+
+    def fix_crcs(b):
+        o = 0
+        while o + 27 <= len(b) and b[o:o + 4] == b"OggS":
+            ns = b[o + 26]
+            ln = 27 + ns + sum(b[o + 27:o + 27 + ns])
+            if o + ln > len(b):
+                break
+            b[o + 22:o + 26] = b"\0\0\0\0"
+            c = 0
+            for x in b[o:o + ln]:
+                c = ((c << 8) & 0xFFFFFFFF) ^ tab[((c >> 24) & 0xFF) ^ x]
+            b[o + 22:o + 26] = c.to_bytes(4, "little")
+            o += ln
+
+    # deterministic first: the 20th audio packet fails after its floor rows and residue were appended (fault injection in
+    # VorbisStream::parse_audio) — the reader must deliver exactly the 20 packets in front of it, consistently
+    for name, want in (("test.stereo44khz", 20), ("test.mono44khz", 7)):
+        r = subprocess.run([probe, "--check", os.path.join(GOLDEN, name + ".ogg")], capture_output=True, text=True,
+                           env=dict(os.environ, PARSEOGGVORBIS_VQ=vq, PARSEOGGVORBIS_TEST_FAIL_AT=str(want)))
+        assert r.returncode == 0 and r.stdout.startswith("consistent batches=1 packets=%d error=1" % want), (r.returncode, r.stdout, r.stderr[-300:])
+    rng = np.random.default_rng(77)
+    base = open(os.path.join(GOLDEN, "test.stereo44khz.ogg"), "rb").read()
+    env = dict(os.environ, PARSEOGGVORBIS_VQ=vq)
+    partial = 0
+    for k in range(40):
+        b = bytearray(base)
+        # the audio pages start behind the three header packets (~ the first 4.3 KB of this file)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(6000, len(b) - 100))
+            b[pos] = int(rng.integers(0, 256))
+        fix_crcs(b)
+        p = tmp_path / ("h%02d.ogg" % k)
+        p.write_bytes(bytes(b))
+        r = subprocess.run([probe, "--check", str(p)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, (k, r.returncode, r.stdout, r.stderr[-300:])
+        assert r.stdout.startswith("consistent")
+        if "error=1" in r.stdout and "packets=0" not in r.stdout:
+            partial += 1
+    assert partial > 0  # some damage did end a stream half way with good packets in front
+
+
 SYNTH = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("synth_") and f.endswith(".ogg"))
 
 
