@@ -462,15 +462,22 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
 #pragma unroll
     for (int t = 0; t < 8; ++t) r[t] = raw[t];
   }
-  // ---- floor curve + product, packet by packet (the lane -> bin map is the same for every packet: bins 2 lane, 2 lane + 1) -------------
+  // ---- floor curve + product (the lane -> bin map is the same for every packet: bins 2 lane, 2 lane + 1) --------------------------------
+  // Two phases over the pass's packets, so that the eight set-ups (ballot, two bpermutes, table write) and then the eight look-up
+  // chains (entry, inverse-dB value) overlap each other instead of running back to back: the eight tables live in the exchange
+  // image, which is idle between the hand-off and the FFT (one table per packet, 512 bytes each).
+  if (ROLE != 0) pair_wait(&partner_flags[1], epoch);  // the partner has read this wave's image: it may be reused
   bool floor_bad = false;
   uint32_t floor_bad_pkt = 0;
+  uint32_t nocurve_mask = 0;
 #pragma unroll
   for (uint32_t t = 0; t < 8; ++t) {
     if (t >= Jp) break;
+    float2* const tab = xb + 64u * t;
     const uint32_t own_t = __builtin_amdgcn_readlane(db[1], t), used_t = __builtin_amdgcn_readlane(db[0], t);
     if (!((own_t >> c) & 1u)) {
-      seg2[lane] = f2(0.f, ((used_t >> c) & 1u) ? 256.5f : 255.5f);
+      nocurve_mask |= 1u << t;
+      tab[lane] = f2(0.f, ((used_t >> c) & 1u) ? 256.5f : 255.5f);
     } else {
       uint32_t v = vrow[t];
       if (lane >= posts) v = 0;
@@ -492,20 +499,32 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
       const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
       const float ady = fabsf(y1 - y0);
       const float a = ady * inv, b = __builtin_fmaf(-ady, x0, 0.5f) * inv;
-      seg2[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);
+      tab[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);
     }
+  }
+  {
     typedef float lds_vf2 __attribute__((ext_vector_type(2)));
-    const bool nocurve = !((own_t >> c) & 1u);
-    const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2;
-    const uint32_t a0 = nocurve ? seg_base : (bseg0 & 0xFFFFu), a1 = nocurve ? seg_base : (bseg0 >> 16);
-    const lds_vf2 e0 = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)a0;
-    const lds_vf2 e1 = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)a1;
+    const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2, xb_base = (uint32_t)(uintptr_t)(lds_u32*)xb;
+    // bseg0 holds the entry addresses inside the wave's own floor table: rebase them onto table t of the image
+    const uint32_t o0 = (bseg0 & 0xFFFFu) - seg_base + xb_base, o1 = (bseg0 >> 16) - seg_base + xb_base;
     const float xf = (float)(2u * lane);
-    const uint32_t i0 = (uint32_t)__builtin_fmaf(xf, e0.x, e0.y), i1 = (uint32_t)__builtin_fmaf(xf + 1.f, e1.x, e1.y);
-    r[t] = f2(r[t].x * T.invdb[i0], r[t].y * T.invdb[i1]);
-    if (TAPC && !nocurve) {  // feature tap "floor1 floor" (hpp:585): the table indices are the rendered curve
-      const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], t) << 32) | __builtin_amdgcn_readlane(da[0], t);
-      ((uint32_t*)(A.curve + off + (size_t)c * MS))[lane] = i0 | (i1 << 16);
+    uint32_t i0[8], i1[8];
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) {
+      if (t >= Jp) break;
+      const lds_vf2 e0 = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)(o0 + 512u * t);
+      const lds_vf2 e1 = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)(o1 + 512u * t);
+      i0[t] = (uint32_t)__builtin_fmaf(xf, e0.x, e0.y);
+      i1[t] = (uint32_t)__builtin_fmaf(xf + 1.f, e1.x, e1.y);
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) {
+      if (t >= Jp) break;
+      r[t] = f2(r[t].x * T.invdb[i0[t]], r[t].y * T.invdb[i1[t]]);
+      if (TAPC && !((nocurve_mask >> t) & 1u)) {  // feature tap "floor1 floor" (hpp:585): the table indices are the rendered curve
+        const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], t) << 32) | __builtin_amdgcn_readlane(da[0], t);
+        ((uint32_t*)(A.curve + off + (size_t)c * MS))[lane] = i0[t] | (i1[t] << 16);
+      }
     }
   }
   // ---- IMDCT x 8 ------------------------------------------------------------------------------------------------------------------------
@@ -515,7 +534,6 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
 #pragma unroll
     for (int t = 0; t < 8; ++t) z[t] = cmulf(f2(r[t].x, __shfl(r[t].y, 63 - (int)lane)), pre);  // X[127 - 2k] lives in lane 63-k
   }
-  if (ROLE != 0) pair_wait(&partner_flags[1], epoch);  // the partner has read this wave's image: the FFT may reuse it
   {
     const uint32_t cl = lane & 7u, hi = lane >> 3;
 #pragma unroll
@@ -699,7 +717,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   uint32_t bseg[8];  // LDS address of the segment entry of each of this lane's 16 bins, 16 bits each; until a floor is seen:
                      // entry 0, which is where a channel without a curve finds its constant entry
 #pragma unroll
+#ifdef VSYN_BSEG_PACK
+  for (int t = 0; t < 8; ++t) bseg[t] = 0u;
+#else
   for (int t = 0; t < 8; ++t) bseg[t] = seg_base | (seg_base << 16);
+#endif
   uint32_t sidx = 0, xsl = 0;       // header index / x of sorted post `lane`
   int cur_floor = -1;
   uint32_t vrow = 0;
@@ -714,10 +736,24 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 
   const uint32_t q0 = qa ? qa - 1 : 0;
   const PktInfo* const ip = A.info + __builtin_amdgcn_readfirstlane(sg.first_packet);
+#ifndef VSYN_NO_WAVE_UNWRAP
   if (A.ys) wave_unwrap(A, xb, lane0, sg, q0, qb, C, c);
+#endif
   PktScalars pi = pkt_load(ip + q0);
   float2 raw[8];  // own channel's residue, requested one packet ahead (mixed runs: when the next block is a long one, too)
   bool raw_ahead = false;  // MIXED: raw[] already holds (or will hold) this packet's residue
+  // MIXED, long blocks: the residue rows come into the hand-off image by LDS-DMA (global_load_lds: no registers), and the NEXT long
+  // block's rows are requested as soon as this block's FFT has released the image — the 128-VGPR mixed path has no registers for a
+  // look-ahead, and without one every long block of a mixed run waited a full memory latency.
+  bool dma_ahead = false;     // this packet's rows are already in flight towards (or in) the image
+  uint32_t dma_younger = 0;   // vector-memory operations issued behind that request: 8 = exactly the fast path's PCM stores
+  auto issue_dma = [&](uint64_t off) {
+    const char* gsrc = (const char*)(A.residue + off) + 16u * lane0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + 1024 * i),
+                                       (__attribute__((address_space(3))) void*)((lds_u32*)xb + 256 * i), 16, 0, 0);
+  };
   if (!MIXED) {
     const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * ML) + lane0;
 #pragma unroll
@@ -809,6 +845,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       vrow_ok = false;
       q += Jp - 1u;
       pi = pkt_load(ip + min(q + 1u, qb - 1u));
+      STAMP(8);  // (mixed runs: a packed short pass, whole)
       continue;
     }
 
@@ -817,6 +854,32 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     float2 r[8];
     // L = rows of the block: all 8 (long) or the first (short); called with a literal so that each copy is straight-line code
     auto residue_rows = [&](const bool L) {
+#ifndef VSYN_NO_MIXED_DMA
+      if (MIXED && L) {
+        if (!dma_ahead) {
+          issue_dma(pi.res_off + (uint64_t)c * ML);
+          dma_younger = 0;
+        }
+        if (dma_younger == 8u) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): the rows have landed; the 8 PCM stores behind them may still fly
+        else vmem_drain();
+        dma_ahead = false;
+        if (ROLE != 0) {
+          pair_post(&my_flags[0], it + 1);
+          pair_wait(&partner_flags[0], it + 1);  // both channels of the pair are in LDS
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float2 own = xb[t * 64 + lane];
+          if (ROLE == 0) {
+            r[t] = own;
+          } else {
+            const float2 oth = pxb[t * 64 + lane];
+            r[t] = ROLE == 1 ? f2(couple_mag(own.x, oth.x), couple_mag(own.y, oth.y)) : f2(couple_ang(oth.x, own.x), couple_ang(oth.y, own.y));
+          }
+        }
+        return;
+      }
+#endif
       if (MIXED && !raw_ahead) {
         const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * (L ? ML : 128u)) + lane;
 #pragma unroll
@@ -886,10 +949,17 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         posts = __builtin_amdgcn_readfirstlane(fc->posts);
         const uint8_t* bs = A.binseg + (size_t)f * ML;
 #pragma unroll
+#ifdef VSYN_BSEG_PACK
+        for (int t = 0; t < 8; t += 2) {
+          const uint32_t two0 = *(const uint16_t*)(bs + 2u * (lane + 64u * t)), two1 = *(const uint16_t*)(bs + 2u * (lane + 64u * (t + 1)));
+          bseg[t >> 1] = two0 | (two1 << 16);
+        }
+#else
         for (int t = 0; t < 8; ++t) {
           const uint32_t two = *(const uint16_t*)(bs + 2u * (lane + 64u * t));  // intervals of bins 2k, 2k+1 (k = lane + 64 t)
           bseg[t] = (seg_base + 8u * (two & 0xFFu)) | ((seg_base + 8u * (two >> 8)) << 16);
         }
+#endif
         const bool in = lane < posts;
         sidx = in ? fc->sorted_idx[lane] : 0u;
         xsl = in ? fc->xs_sorted[lane] : 0u;
@@ -944,7 +1014,14 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int b = 4 * grp + i;
+#ifdef VSYN_BSEG_PACK
+          // four interval numbers per register (half the registers, one more VALU op per bin): the steady path alone then needs 122
+          // VGPRs instead of 126 — still above the 120 at which a 32-VGPR pre-kernel wave could co-reside; off
+          const uint32_t w4 = (b & 2) ? (bseg[b >> 2] >> 16) : bseg[b >> 2];
+          const uint32_t addr = seg_base + 8u * ((b & 1) ? ((w4 >> 8) & 0xFFu) : (w4 & 0xFFu));
+#else
           const uint32_t addr = (b & 1) ? (bseg[b >> 1] >> 16) : (bseg[b >> 1] & 0xFFFFu);  // one VALU op per bin
+#endif
           typedef float lds_vf2 __attribute__((ext_vector_type(2)));
           const lds_vf2 ev = *(const __attribute__((address_space(3))) lds_vf2*)(uintptr_t)addr;
           sgm[i] = f2(ev.x, ev.y);
@@ -1000,6 +1077,19 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       __builtin_amdgcn_s_setprio(0);
 #endif
       STAMP(6);  // FFT-512
+#ifndef VSYN_NO_MIXED_DMA
+      if (MIXED) {
+        // the image is free until the next packet's hand-off (the partner finished with it before the FFT): request the next long
+        // block's rows into it now
+        dma_ahead = has_next && nlng && !pin.bad;
+        dma_younger = 0xFFu;
+        if (dma_ahead) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own reads of the image are done
+          issue_dma(pin.res_off + (uint64_t)c * ML);
+          dma_younger = 0;
+        }
+      }
+#endif
 #pragma unroll
       for (int k = 0; k < 8; ++k) z[k] = cmulf(z[k], T.post[k][lane]);
 
@@ -1083,7 +1173,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       // Everything this wave has in flight here is LOADS issued long ago (residue and coded row of packet q+1): finish them before
       // the PCM stores go out, so that no later wait in the loop (the compiler places the loop-carried copies of those registers
       // behind the stores, where only vmcnt(0) is safe on every path) ever waits for a store. The stores are never waited for.
+#ifndef VSYN_NO_MIXED_DMA
+      if (!MIXED) vmem_drain();  // (mixed runs: the next block's rows are in flight on purpose; they are waited for by count)
+#else
       vmem_drain();
+#endif
       STAMP(7);  // post-rotation, window reads, overlap arithmetic, mirror exchange of the outputs
       // sample s = 2*kappa + 128*j of (lane, kh = 4 + j): two lane pointers, every store at an immediate offset
       if (VSYN_KNOCKOUT & 8) {
@@ -1092,6 +1186,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         for (int j = 0; j < 4; ++j) acc += oh_s[j] + n_s[j] + n_m[j] + oh_m[j];
         if (acc == 12345.678f) out[lane] = acc;  // keeps the arithmetic alive without the stores
       } else if (fast_store) {
+        if (MIXED && dma_younger == 0u) dma_younger = 8u;
         float* up = out + 2u * kappa;            // samples s, s+1
         float* dn = out + 1022u - 2u * kappa;    // samples 1022-s, 1023-s
 #pragma unroll
@@ -1100,6 +1195,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
           *(float2*)(dn - 128 * j) = f2(n_m[j], oh_m[j]);
         }
       } else if (emit) {
+        if (MIXED) dma_younger = 0xFFu;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           // frames of samples s, s+1, 1022-s, 1023-s (a frame before the chunk wraps around and is never < emit)
@@ -1112,6 +1208,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         }
       }
       STAMP(8);  // PCM stores issued
+      if (MIXED && (last_of_segment || hand_over)) dma_younger = 0xFFu;
       if (last_of_segment || hand_over) {
         // the windowed right half in natural order: sample s of point k at position s.  Last block of the segment: all of it
         // into the stream's carry buffer for the next submit.  Before a short block: frames 0..447 are final (nothing else
@@ -1160,7 +1257,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     pi = pin;
   }
 #ifdef VSYN_STAMPS
-  if (!MIXED && lane0 == 0) {
+  if (lane0 == 0) {
     const uint32_t unit = blockIdx.x * FUSED_WAVES + (threadIdx.x >> 6);
     if (unit < 8192)
       for (int i = 0; i < VSYN_NSTAMPS; ++i) g_vsyn_stamps[unit][i] = i == VSYN_NSTAMPS - 1 ? (unsigned long long)(qb - q0) : st_acc[i];

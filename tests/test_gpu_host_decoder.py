@@ -326,6 +326,6 @@ def test_error_in_mid_stream_still_delivers_the_packets_before_it(vq, tmp_path):
     assert len(packets) == k
     want = int(b["emit_len"][:k].sum())
     for c in range(spec.channels):
-        got = np.concatenate(pcm[c]) if len(pcm[c]) else np.zeros(0, np.float32)
+        got = np.concatenate([np.atleast_1d(v) for v in pcm[c]]) if len(pcm[c]) else np.zeros(0, np.float32)
         assert got.shape[0] == want
         assert np.abs(got - b["pcm"][c, :want]).max() < TOL
