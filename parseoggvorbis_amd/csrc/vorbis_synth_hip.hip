@@ -380,12 +380,18 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   if (u_supported(h->H, h->host_const.data()) && !getenv("VSYN_NO_U")) {
     const bool want = !(h->fused_mask & 2u) || (getenv("VSYN_U_MIXED") && atoi(getenv("VSYN_U_MIXED")));
     if (want) {
-      if ((e = u_tables_create(h->H, h->host_const.data(), &h->utab)) != hipSuccess) {
+      e = u_tables_create(h->H, h->host_const.data(), &h->utab);
+      if (e == hipSuccess) {
+        h->u_mixed = true;
+        h->fused_mask |= 2u;
+      } else if (e == hipErrorInvalidValue) {
+        // the setup does not fit (its channel waves plus the tables of an 8192-sample block exceed one CU's LDS): staged kernels
+        u_tables_destroy(&h->utab);
+        (void)hipGetLastError();
+      } else {
         fail(err, VSYN_ERR_HIP, "generic fused table upload failed: %s", hipGetErrorString(e));
         return cleanup(VSYN_ERR_HIP);
       }
-      h->u_mixed = true;
-      h->fused_mask |= 2u;
     }
   }
   h->fused_ok = h->fused_mask != 0;

@@ -45,11 +45,12 @@ struct UBig {
   float win[2][2][NS][8][64];   // [window flag][0: at s, 1: at M-1-s][u'][c'][lane]
 };
 
-// per-wave LDS block (dynamic): exchange image | floor entries | packet info of the pass | hand-off flags | carry image
+// per-wave LDS block (dynamic): exchange image | floor entries | packet info of the pass | next descriptors | hand-off flags | carry image
 #define U_XB_BYTES 4608u
 #define U_SEG_OFF U_XB_BYTES
 #define U_PINF_OFF (U_SEG_OFF + 512u)
-#define U_FLAG_OFF (U_PINF_OFF + 256u)
+#define U_DNEXT_OFF (U_PINF_OFF + 256u)   /* descriptors of the next pass's candidates, 8 x 32 B, filled by LDS-DMA */
+#define U_FLAG_OFF (U_DNEXT_OFF + 256u)
 #define U_CBUF_OFF (U_FLAG_OFF + 16u)
 #define U_MAX_J 8u
 #ifndef U_MAX_THREADS
@@ -164,16 +165,17 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
   uint32_t bsegw[4] = {0, 0, 0, 0};  // sorted-post interval of this lane's bins 4 lane + 256 i + {0..3}, one byte each
 
   // packet descriptors of the candidates of the pass to be formed next: lane j < 8 holds packet (start) + j
-  u_u32x4 nfa = {0, 0, 0, 0}, nfb = {0, 0, 0, 0};
+  // They come by LDS-DMA (one 4-byte piece per lane: 256 contiguous bytes = descriptors qq .. qq+7; the workspace has slack behind
+  // its last packet, and candidates beyond the run are masked) — in registers they were eight VGPRs live across the whole pass.
+  lds_u32* const dnext = (lds_u32*)(wmem + U_DNEXT_OFF);
   auto fetch_info = [&](uint32_t qq) {
-    const uint32_t idx = min(qq + (lane & 7u), qb - 1u);
-    const u_u32x4* p = (const u_u32x4*)(ip + idx);
-    nfa = p[0];
-    nfb = p[1];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)(ip + qq) + 4u * lane),
+                                     (__attribute__((address_space(3))) void*)dnext, 4, 0, 0);
   };
   // Form the pass that starts at packet qs from the descriptors in nfa/nfb (already landed): consecutive valid packets of one size
   // and mapping, at most J; packet table into pinf[buf]; then request the descriptors behind it.
   auto form = [&](uint32_t qs, uint32_t buf) -> UPass {
+    u_u32x4 nfa = *(const u_lds_u32x4*)(dnext + 8u * (lane & 7u)), nfb = *(const u_lds_u32x4*)(dnext + 8u * (lane & 7u) + 4u);
     UPass ps;
     ps.after_bad = false;
     ps.valid = false;
@@ -186,6 +188,8 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
       if (qs < qb) {
         fetch_info(qs);
         vmem_drain();
+        nfa = *(const u_lds_u32x4*)(dnext + 8u * (lane & 7u));
+        nfb = *(const u_lds_u32x4*)(dnext + 8u * (lane & 7u) + 4u);
       }
     }
     ps.q = qs;
@@ -448,10 +452,10 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
       uint32_t next_M = 0, next_emit = 0, next_out = 0;
       vmem_drain();
       if (qn < qb) {
-        const uint32_t nbad = __builtin_amdgcn_readfirstlane((nfb[3] >> 8) & 0xFFu), nlng = __builtin_amdgcn_readfirstlane((nfb[2] >> 16) & 0xFFu);
+        const uint32_t nbad = __builtin_amdgcn_readfirstlane((dnext[7] >> 8) & 0xFFu), nlng = __builtin_amdgcn_readfirstlane((dnext[6] >> 16) & 0xFFu);
         next_M = nbad ? 0u : (2u << (nlng ? lgp[1] : lgp[0]));
-        next_emit = __builtin_amdgcn_readfirstlane(qn < qa ? 0u : nfa[3]);
-        next_out = __builtin_amdgcn_readfirstlane(nfa[2]);
+        next_emit = __builtin_amdgcn_readfirstlane(qn < qa ? 0u : dnext[3]);
+        next_out = __builtin_amdgcn_readfirstlane(dnext[2]);
       }
       const bool hand_over = next_M && next_M != Mb;
       const uint32_t cur_next_long = (widx_b >> 1) & 1u;
@@ -852,11 +856,11 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
     vmem_drain();
     const bool last_of_segment = qn == num;
     uint32_t next_M = 0, next_emit = 0, next_out = 0;
-    if (qn < qb) {  // nfa/nfb hold the descriptors behind this pass by now
-      const uint32_t nbad = __builtin_amdgcn_readfirstlane((nfb[3] >> 8) & 0xFFu), nlng = __builtin_amdgcn_readfirstlane((nfb[2] >> 16) & 0xFFu);
+    if (qn < qb) {  // the descriptors behind this pass have landed by now (drained above)
+      const uint32_t nbad = __builtin_amdgcn_readfirstlane((dnext[7] >> 8) & 0xFFu), nlng = __builtin_amdgcn_readfirstlane((dnext[6] >> 16) & 0xFFu);
       next_M = nbad ? 0u : (2u << (nlng ? lgp[1] : lgp[0]));
-      next_emit = __builtin_amdgcn_readfirstlane(qn < qa ? 0u : nfa[3]);
-      next_out = __builtin_amdgcn_readfirstlane(nfa[2]);
+      next_emit = __builtin_amdgcn_readfirstlane(qn < qa ? 0u : dnext[3]);
+      next_out = __builtin_amdgcn_readfirstlane(dnext[2]);
     }
     const bool hand_over = next_M && next_M != M;
     float oh_s[4], oh_m[4], n_s[4], n_m[4];
@@ -1133,7 +1137,7 @@ static inline hipError_t u_tables_create(const ConstHeader& H, const uint8_t* ho
   e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ut->table_bytes + ut->waves_per_block * ut->wave_bytes));
   if (e != hipSuccess && getenv("VSYN_DEBUG"))
     fprintf(stderr, "vsyn: hipFuncSetAttribute(%u B dynamic LDS) failed: %s\n", ut->table_bytes + ut->waves_per_block * ut->wave_bytes, hipGetErrorString(e));
-  return e;
+  return e == hipSuccess ? hipSuccess : hipErrorInvalidValue;
 }
 
 static inline void u_tables_destroy(UTables* ut) {
