@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="diagnostic builds only (VSYN_KNOCKOUT): do not gate on the oracle spot check")
     ap.add_argument("--staged", action="store_true", help="time the staged kernels instead of the fused one")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="diagnostic: no HIP events around the dominant kernel (roofline.achieved is then null)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not let a submit's pre-kernels overlap the previous submit (diagnostic: standalone kernel times)")
     args = ap.parse_args()
@@ -401,7 +403,7 @@ def main():
     fl, bad = gpu.sync_status(stream)
     assert fl == 0, "device flagged the synthetic batch: 0x%x at packet %d" % (fl, bad)
 
-    gpu.profile({"config4": 2, "config3_vq": 3}.get(args.workload, 1))
+    gpu.profile(0 if args.no_kernel_timing else {"config4": 2, "config3_vq": 3}.get(args.workload, 1))
     gpu.profile_read()
     barrier()
     torch.cuda.synchronize()
@@ -435,7 +437,7 @@ def main():
                 e0, ne, c0 = int(vqp["entry_off"][q]), int(vqp["num_entries"][q]), int(vqp["cls_off"][q])
                 c1 = int(vqp["cls_off"][q + 1]) if q + 1 < len(vqp) else cls.size
                 rc_o, want_r = ob.residue_vq(vqs, 1, spec.channels, spec.blocksize1 // 2, 3, cls[c0:c1], ent[e0:e0 + ne])
-                assert rc_o == 0 and np.array_equal(want_r.view(np.uint32), hr[q * per_pk:(q + 1) * per_pk].view(np.uint32)), q
+                assert args.no_check or (rc_o == 0 and np.array_equal(want_r.view(np.uint32), hr[q * per_pk:(q + 1) * per_pk].view(np.uint32))), q
         orc = OracleSynth(spec, ns)
         want = orc.submit_host(hp, hs, hy, hr, b["plane"])
         got = pcm[:ns].cpu().numpy()

@@ -99,6 +99,8 @@ struct vsyn_handle {
   uint8_t* d_vq = nullptr;             // residue VQ stage: VqHeader, books, residues, maps, value pool (vsyn_attach_vq)
   uint32_t vq_lds_bytes = 0;           // dynamic LDS of the residue VQ kernel
   uint32_t vq_grid = 0;                // workgroups of the VQ kernel that are resident at once (its grid: every wave walks packets)
+  uint32_t vq_waves = 1;               // waves per workgroup: 1, or (value tables shared in LDS) several
+  bool vq_tables_in_lds = false;
   uint32_t last_S = 0, last_wb = 0;    // segments / workspace half of the most recent submit (vsyn_pcm_interleave_device)
   DevBuf<vsyn_vq_packet> st_vqpk;      // vsyn_submit_host_vq staging
   DevBuf<uint8_t> st_cls;
@@ -363,10 +365,13 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   HC(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   HC(hipStreamCreateWithFlags(&h->pre, hipStreamNonBlocking));
   HC(hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking));
-  HC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  // ordering events between this handle's own streams: device-scope release is enough (the one host read,
+  // vsyn_sync_status, synchronises its stream); the system-scope fence of a default event costs ~3 us per submit
+  const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+  HC(hipEventCreateWithFlags(&h->ev_join, evf));
   for (int b = 0; b < 2; ++b) {
-    HC(hipEventCreateWithFlags(&h->ev_pre_done[b], hipEventDisableTiming));
-    HC(hipEventCreateWithFlags(&h->ev_main_done[b], hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&h->ev_pre_done[b], evf));
+    HC(hipEventCreateWithFlags(&h->ev_main_done[b], evf));
   }
   HC(h->ws_count.ensure(4));
   HC(hipMemset(h->ws_count.p, 0, sizeof(uint32_t) * 4));
@@ -404,6 +409,26 @@ void vsyn_destroy(vsyn_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+#ifdef VQ_STAMPS
+  {  // diagnostic build: the residue VQ kernel's cycles per phase and packet (last launch), averaged over its waves
+    static unsigned long long host[8192][VQ_NSTAMPS];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_vq_stamps), sizeof(host)) == hipSuccess) {
+      double sum[VQ_NSTAMPS] = {0};
+      unsigned long long pk = 0, waves = 0;
+      for (int u = 0; u < 8192; ++u) {
+        if (!host[u][VQ_NSTAMPS - 1]) continue;
+        ++waves;
+        pk += host[u][VQ_NSTAMPS - 1];
+        for (int i = 0; i + 1 < VQ_NSTAMPS; ++i) sum[i] += (double)host[u][i];
+      }
+      if (pk) {
+        fprintf(stderr, "[vq stamps] %llu waves, %.1f packets each; s_memtime ticks per packet:", waves, (double)pk / waves);
+        for (int i = 0; i + 1 < VQ_NSTAMPS; ++i) fprintf(stderr, " %d:%.0f", i, sum[i] / pk);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+#endif
 #ifdef VSYN_STAMPS
   {  // diagnostic build: per-phase cycles of the LAST launch's steady runs, averaged over the waves that ran one
     static unsigned long long host[8192][VSYN_NSTAMPS];
@@ -493,9 +518,10 @@ static hipError_t profile_begin(vsyn_handle* h, hipStream_t s, const char* name)
   if (!h->profile) return hipSuccess;
   if (h->events_used == h->events.size()) {
     hipEvent_t a, b;
-    hipError_t e = hipEventCreate(&a);
+    const unsigned pf = hipEventDisableSystemFence;  // timestamps only: no cache flush around the timed kernel
+    hipError_t e = hipEventCreateWithFlags(&a, pf);
     if (e != hipSuccess) return e;
-    e = hipEventCreate(&b);
+    e = hipEventCreateWithFlags(&b, pf);
     if (e != hipSuccess) return e;
     h->events.emplace_back(a, b);
   }
@@ -627,8 +653,12 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   }
   if (d_vq) {
     if (h->profile_which == 3) HIPCHK(profile_begin(h, ps, "vsyn_residue_vq_kernel"));
-    vsyn_residue_vq_kernel<<<std::min<uint32_t>(P, h->vq_grid), VQ_THREADS, h->vq_lds_bytes, ps>>>(
-        h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
+    if (h->vq_tables_in_lds)
+      vsyn_residue_vq_kernel<true><<<std::min<uint32_t>((P + h->vq_waves - 1u) / h->vq_waves, h->vq_grid), VQ_THREADS * h->vq_waves, h->vq_lds_bytes, ps>>>(
+          h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
+    else
+      vsyn_residue_vq_kernel<false><<<std::min<uint32_t>(P, h->vq_grid), VQ_THREADS, h->vq_lds_bytes, ps>>>(
+          h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
   }
   if (d_vq && h->profile_which == 3) HIPCHK(profile_end(h, ps));
   HIPCHK(hipEventRecord(h->ev_pre_done[wb], ps));
@@ -749,11 +779,47 @@ int vsyn_attach_vq(vsyn_handle* h, const vsyn_vq_setup* vq, const char** err) {
   {
     const VqHeader* vh = (const VqHeader*)block.data();
     uint32_t lds_off[7];
-    h->vq_lds_bytes = vq_lds_layout(vh->max_slots, vh->max_classes, lds_off);
-    int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vsyn_residue_vq_kernel, VQ_THREADS, h->vq_lds_bytes));
-    if (const char* e = getenv("VSYN_VQ_WG_PER_CU")) per_cu = atoi(e);
-    h->vq_grid = (uint32_t)h->num_cus * (uint32_t)std::max(per_cu, 1);
+    const uint32_t wave_bytes = vq_lds_layout(vh->max_slots, vh->max_classes, lds_off);
+    h->vq_tables_in_lds = false;
+    h->vq_waves = 1;
+    if (vh->img_floats && !(getenv("VSYN_VQ_NO_LDS_TABLES") && atoi(getenv("VSYN_VQ_NO_LDS_TABLES")))) {
+      // value tables in LDS, one copy per workgroup: k workgroups of w waves per CU, the pair that keeps most waves resident
+      const uint32_t tab_bytes = vq_align16(vh->img_floats * 4u);
+      hipFuncAttributes fa;
+      HIPCHK(hipFuncGetAttributes(&fa, (const void*)vsyn_residue_vq_kernel<true>));
+      const uint32_t regs = ((uint32_t)std::max(fa.numRegs, 1) + 7u) / 8u * 8u;  // allocation granule 8, 512 per SIMD lane
+      const uint32_t cu_waves = 4u * std::min<uint32_t>(8u, 512u / regs);
+      uint32_t best_k = 0, best_w = 0;
+      for (uint32_t k = 1; k <= 4; ++k) {
+        // (several workgroups per CU: measured co-resident up to 2 x 67 KB, not at 2 x 73 KB — plan those against 128 KB)
+        const uint32_t budget = k == 1 ? 156u * 1024u : 128u * 1024u;
+        if (budget / k <= tab_bytes + wave_bytes) break;
+        const uint32_t w = std::min<uint32_t>({16u, (budget / k - tab_bytes) / wave_bytes, cu_waves / k});
+        if (w && k * w > best_k * best_w) best_k = k, best_w = w;
+      }
+      if (const char* e = getenv("VSYN_VQ_WAVES_PER_WG")) best_w = (uint32_t)std::max(1, std::min(16, atoi(e)));
+      if (best_w) {
+        const uint32_t lds = tab_bytes + best_w * wave_bytes;
+        HIPCHK(hipFuncSetAttribute((const void*)vsyn_residue_vq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vsyn_residue_vq_kernel<true>, (int)(VQ_THREADS * best_w), lds));
+        if (per_cu > 0) {
+          h->vq_tables_in_lds = true;
+          h->vq_waves = best_w;
+          h->vq_lds_bytes = lds;
+          if (const char* e = getenv("VSYN_VQ_WG_PER_CU")) per_cu = atoi(e);
+          h->vq_grid = (uint32_t)h->num_cus * (uint32_t)std::max(per_cu, 1);
+          if (getenv("VSYN_DEBUG")) fprintf(stderr, "[vsyn] vq: tables in LDS (%u B), %u waves per workgroup, %d workgroups per CU, %u B LDS\n", tab_bytes, best_w, per_cu, lds);
+        }
+      }
+    }
+    if (!h->vq_tables_in_lds) {
+      h->vq_lds_bytes = wave_bytes;
+      int per_cu = 0;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vsyn_residue_vq_kernel<false>, VQ_THREADS, h->vq_lds_bytes));
+      if (const char* e = getenv("VSYN_VQ_WG_PER_CU")) per_cu = atoi(e);
+      h->vq_grid = (uint32_t)h->num_cus * (uint32_t)std::max(per_cu, 1);
+    }
   }
   return VSYN_OK;
 }

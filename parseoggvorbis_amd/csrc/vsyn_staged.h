@@ -445,6 +445,7 @@ __device__ __forceinline__ uint32_t predict_post(uint32_t ylo, uint32_t yhi, uin
 }
 
 #define UNWRAP_THREADS 128
+#define UNWRAP_REG_POSTS 32
 __global__ void __launch_bounds__(UNWRAP_THREADS)
 vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                          const PktInfo* __restrict__ info, const uint16_t* __restrict__ ys, uint16_t* __restrict__ fy_out,
@@ -464,6 +465,79 @@ vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const uint3
     const FloorConst* fc = floor_of(cb, map_of(cb, pi.mapping)->chfloor[c]);
     uint16_t* out = fy_out + (size_t)gid * stride;
     const uint32_t posts = fc->posts, range = fc->range, mult = fc->mult;
+    // When every active row of the wavefront uses the same floor (always, unless block sizes alternate inside the 64 rows) the
+    // per-post constants are wave-uniform: read them through the scalar unit (constant address space -> s_load, scalar cache)
+    // instead of 64 identical per-lane loads per post.
+    const uint64_t fc_bits = (uint64_t)(uintptr_t)fc;
+    const uint64_t fc_first = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)fc_bits) |
+                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fc_bits >> 32)) << 32);
+    const bool fc_uniform = __all(fc_bits == fc_first);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) u32x4* const_pk;
+#ifndef VSYN_NO_UNWRAP_REGS
+    // Up to 32 posts (every floor libvorbis writes for the common modes): the row lives in a per-thread register array
+    // indexed by the wave-uniform neighbour indices (s_set_gpr_idx / v_movrel), so the serial chain over the posts is a
+    // few dozen VALU cycles per post instead of three dependent LDS round trips. 32 is where the compiler still keeps the
+    // array in registers; longer floors take the LDS path below.
+    if (fc_uniform && __builtin_amdgcn_readfirstlane(posts) <= UNWRAP_REG_POSTS) {
+      const FloorConst* fcu = (const FloorConst*)(uintptr_t)fc_first;
+      const uint32_t posts_u = __builtin_amdgcn_readfirstlane(posts);
+      uint32_t f[UNWRAP_REG_POSTS];
+      const uint2* in8 = (const uint2*)(ys + (size_t)gid * stride);
+#pragma unroll
+      for (uint32_t j = 0; j < UNWRAP_REG_POSTS / 4; ++j) {
+        uint2 w = make_uint2(0u, 0u);
+        if (j * 4 < posts_u) w = in8[j];
+        f[4 * j + 0] = w.x & 0xFFFFu;
+        f[4 * j + 1] = w.x >> 16;
+        f[4 * j + 2] = w.y & 0xFFFFu;
+        f[4 * j + 3] = w.y >> 16;
+      }
+      uint32_t flags = 3;
+      bool bad = false;
+      u32x4 kn = *(const_pk)(uintptr_t)&fcu->pk[2];
+      for (uint32_t i = 2; i < posts_u; ++i) {
+        const u32x4 kq = kn;
+        kn = *(const_pk)(uintptr_t)&fcu->pk[i + 1];  // next post's constants while this one computes (pk[] has 65 entries)
+        const uint32_t lo = kq.x & 0xFFFFu, hi = kq.x >> 16;
+        const uint32_t val = f[i], ylo = f[lo], yhi = f[hi];
+        const uint32_t dxi = kq.y & 0xFFFFu, adx = kq.y >> 16;
+        const bool up = yhi >= ylo;
+        const uint32_t ady = up ? yhi - ylo : ylo - yhi;
+        const uint32_t prod = ady * dxi;
+        uint32_t off = (uint32_t)(((float)prod + 0.5f) * __uint_as_float(kq.z));
+        if (__any(prod >= (1u << 21))) off = prod >= (1u << 21) ? prod / adx : off;
+        const uint32_t predicted = up ? ylo + off : ylo - off;
+        const bool ok = predicted <= range;  // hpp:536
+        const uint32_t pr = ok ? predicted : 0u;
+        const uint32_t high_room = range - pr, low_room = pr;
+        const uint32_t room = min(high_room, low_room) * 2;
+        const uint32_t big = high_room > low_room ? val - low_room + pr : pr - val + high_room - 1;
+        const uint32_t small = (val & 1u) ? pr - (val + 1) / 2 : pr + val / 2;
+        const uint32_t fn = val == 0 ? pr : (val >= room ? big : small);
+        const uint32_t touched = (1u << lo) | (1u << hi) | (1u << i);  // lo, hi < i < 32
+        flags |= val != 0 ? touched : 0u;
+        bad = bad || !ok;
+        f[i] = bad ? 0u : fn;  // after the first out-of-range prediction the row is dropped; keep the chain tame
+      }
+      uint2* out8 = (uint2*)out;
+      if (bad) raise_status(status, VSYN_ST_FLOOR_RANGE, p);
+#pragma unroll
+      for (uint32_t j = 0; j < UNWRAP_REG_POSTS / 4; ++j) {
+        if (j * 4 >= posts_u) break;
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+          const uint32_t i = 4 * j + e;
+          uint32_t v = f[i] * mult;  // hpp:573,578
+          if (v > 0x7FFFu || f[i] > 0x7FFFu) v = 0x7FFFu;
+          w[e] = i < posts_u ? (bad ? 0x8000u : (v | (((flags >> i) & 1u) << 15))) : 0u;
+        }
+        out8[j] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+      }
+      continue;
+    }
+#endif
     {  // whole coded row up front (16-byte loads; rows are 8-byte aligned multiples of 4 posts), values parked in LDS
       const uint2* in8 = (const uint2*)(ys + (size_t)gid * stride);
       for (uint32_t j = 0; j * 4 < posts; ++j) {
@@ -504,15 +578,7 @@ vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const uint3
       s_fy[i][t] = f;
       return ok;
     };
-    // When every active row of the wavefront uses the same floor (always, unless block sizes alternate inside the 64 rows) the
-    // per-post constants are wave-uniform: read them through the scalar unit (constant address space -> s_load, scalar cache)
-    // instead of 64 identical per-lane loads per post — those loads, not the LDS chain, set this kernel's pace.
-    const uint64_t fc_bits = (uint64_t)(uintptr_t)fc;
-    const uint64_t fc_first = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)fc_bits) |
-                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fc_bits >> 32)) << 32);
-    if (__all(fc_bits == fc_first)) {
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      typedef const __attribute__((address_space(4))) u32x4* const_pk;
+    if (fc_uniform) {
       const FloorConst* fcu = (const FloorConst*)(uintptr_t)fc_first;
       const uint32_t posts_u = __builtin_amdgcn_readfirstlane(posts);
       for (uint32_t i = 2; i < posts_u && !bad; ++i) {

@@ -40,16 +40,19 @@
 #define VQ_GROUP 8
 #define VQ_MAX_SLOTS 8192  /* (pass, partition, channel) slots of one submap vector; vsyn_attach_vq enforces it. The kernel's
                               dynamic LDS is sized to the largest count the attached setup can produce (fixtures: 400) */
+#define VQ_IMG_MAX_BYTES 49152u   /* LDS table image (one copy per workgroup): setups whose tables exceed this keep them in global memory */
 #define VQ_ENT_CAP 2048    /* a packet with at most this many entry numbers has them staged in LDS by direct-to-LDS loads
                               (stereo long blocks of the fixture: ~1400); longer ones read them from global memory */
 
 struct VqBook {       // 16 bytes
   uint32_t dims, entries;
   uint32_t table_off;  // float index into the pool; 0xFFFFFFFF: no value table
-  uint32_t pad;
+  uint32_t lds_off;    // float index into the LDS table image (VqHeader::off_img); 0xFFFFFFFF: not in the image
 };
 struct VqResidue {
-  uint32_t type, begin, end, psize, nclass, classwords, pass_mask, pad1;  // pass_mask bit k: some class has a codebook in pass k
+  uint32_t type, begin, end, psize, nclass, classwords;
+  uint32_t pass_mask;  // bit k: some class has a codebook in pass k
+  uint32_t kinds;      // VQ_KIND_*: the routes of the accumulate phase this residue can need
   int16_t books[64 * 8];
 };
 struct VqMap {        // all fields the per-packet code reads are dwords: they come in through the scalar cache
@@ -64,6 +67,7 @@ struct VqHeader {
   uint32_t off_books, off_residues, off_maps, off_pool;  // byte offsets from the block base
   uint32_t pool_floats, total_bytes;
   uint32_t max_slots, max_classes;  // largest slot count of any submap vector at blocksize1 / class count of any residue: LDS sizing
+  uint32_t off_img, img_floats;     // the value tables in the form the LDS-table kernel keeps per workgroup (0 floats: setup not eligible)
 };
 
 // Dynamic LDS of one workgroup (= one wavefront), shared between the host (launch) and the kernel (carving):
@@ -89,8 +93,20 @@ static inline __host__ __device__ uint32_t vq_lds_layout(uint32_t max_slots, uin
 }
 
 #ifdef __HIPCC__
+#ifdef VQ_STAMPS  /* diagnostic build: cycles per phase of the packet walk, summed per wave (printed by vsyn_destroy) */
+#define VQ_NSTAMPS 8
+__device__ unsigned long long g_vq_stamps[8192][VQ_NSTAMPS];
+#define VQ_STAMP(i)                                                                \
+  do {                                                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+    vq_st[i] += now_ - vq_t;                                                       \
+    vq_t = now_;                                                                   \
+  } while (0)
+#else
+#define VQ_STAMP(i) do { } while (0)
+#endif
 struct VqCp {  // per (class, pass)
-  uint32_t tab;  // float index of the value table in the pool
+  uint32_t tab;  // float index of the value table: in the pool, or (LDS-table kernel) in the workgroup's table image
   uint32_t inf;  // bits 0..15 entry count - 1; 16..19 log2(vector length) if VQ_CP_FAST; VQ_CP_* flags
 };
 #define VQ_CP_FAST 0x01000000u  /* 8.6.4 layout (format 1 / 2) and a power-of-two vector length */
@@ -131,7 +147,7 @@ __device__ __noinline__ uint32_t vq_general_index(uint32_t type, uint32_t psize,
 
 // Everything one submap vector needs in the accumulate phase (wave-uniform)
 struct VqSubCtx {
-  uint32_t type, psize, vch, nch, npj, parts, lim_begin, len, n2, gpp, pass_mask;
+  uint32_t type, psize, vch, nch, npj, parts, lim_begin, len, n2, gpp, pass_mask, kinds;
   uint32_t chan0, chan1;
   uint32_t ent_base;        // first entry of the submap relative to the packet's first entry
   uint32_t poff_lanes;      // lane k < 8: first entry of pass k relative to ent_base (read with readlane)
@@ -140,151 +156,196 @@ struct VqSubCtx {
 
 // The accumulate phase: a lane owns VQ_GROUP consecutive elements of one partition of one vector and adds their up-to-8
 // contributions in pass order (hpp:711) in registers. ENT_LDS: the packet's entries sit in s_ent, otherwise in eg[].
-template <bool ENT_LDS>
+// A lane works on VQ_BATCH groups (64 groups apart) before it stores any of them: vector-memory operations complete in order, so a
+// table load issued behind a store returns only after that store has been acknowledged — batching leaves one such boundary per
+// 256 groups instead of one per 64.
+// What the kernel pays for here is the scalar unit (one per CU, ~1400 scalar instructions per packet before this form: exec-mask
+// bookkeeping of the per-lane vector-length variants), so: which variants a residue can need at all is a setup fact
+// (VqResidue::kinds, wave-uniform branches), lengths >= 4 share one route, and "entry out of range" is tracked as a sign bit in a
+// vector register instead of a lane mask.
+#ifndef VQ_BATCH
+#define VQ_BATCH 1
+#endif
+#define VQ_KIND_V4 1u   /* 8.6.4 layout, vector length a power of two >= 4 */
+#define VQ_KIND_V2 2u   /* ... length 2 */
+#define VQ_KIND_V1 4u   /* ... length 1 */
+#define VQ_KIND_GEN 8u  /* format 0, other lengths, or a partition size that is not a multiple of VQ_GROUP */
+template <bool ENT_LDS, bool TLDS>
 __device__ __forceinline__ bool vq_accumulate(const VqSubCtx& X, const uint32_t lane, const bool bad, const VqCp* s_cp,
                                                const uint16_t* s_pp, const vq_u32x4* s_start, const uint16_t* s_ent, const uint8_t* s_vm,
                                                const uint8_t* s_cls, const uint8_t* s_chan, const uint16_t* __restrict__ eg,
-                                               const __amdgpu_buffer_rsrc_t pool, float* __restrict__ out) {
+                                               const __amdgpu_buffer_rsrc_t pool, const float* s_tab, float* __restrict__ out) {
   auto entry = [&](uint32_t i) -> uint32_t { return ENT_LDS ? (uint32_t)s_ent[X.ent_shift + i] : (uint32_t)eg[i]; };
+  typedef float vq_f4 __attribute__((ext_vector_type(4)));
+  typedef float vq_f2 __attribute__((ext_vector_type(2)));
   const uint32_t groups = X.npj * X.gpp;
   const bool full8 = (X.psize & (VQ_GROUP - 1u)) == 0u;
   const uint32_t q64 = VQ_THREADS / X.gpp, r64 = VQ_THREADS - q64 * X.gpp;
-  uint32_t pj = lane / X.gpp, wq = lane - pj * X.gpp;
-  bool bad_entry = false;
-  for (uint32_t gi = lane; gi < groups; gi += VQ_THREADS) {
-    const uint32_t w0 = wq * VQ_GROUP;
-    uint32_t pc = pj, j = 0;
-    if (X.vch != 1u) {
-      pc = pj / X.vch;
-      j = pj - pc * X.vch;
+  uint32_t pj_run = lane / X.gpp, wq_run = lane - pj_run * X.gpp;
+  uint32_t over = 0;  // sign bit: some entry number was beyond its book
+  bool bad_general = false;
+  for (uint32_t base = 0; base < groups; base += VQ_THREADS * VQ_BATCH) {
+    float acc[VQ_BATCH][VQ_GROUP];
+    uint32_t pjs[VQ_BATCH], w0s[VQ_BATCH];
+#pragma unroll
+    for (int u = 0; u < VQ_BATCH; ++u) {
+      pjs[u] = pj_run;
+      w0s[u] = wq_run * VQ_GROUP;
+      pj_run += q64;
+      wq_run += r64;
+      if (wq_run >= X.gpp) {
+        wq_run -= X.gpp;
+        ++pj_run;
+      }
     }
-    const uint32_t cnt_el = full8 ? (uint32_t)VQ_GROUP : min((uint32_t)VQ_GROUP, X.psize - w0);
-    float acc[VQ_GROUP];
+    uint32_t cs[VQ_BATCH], vms[VQ_BATCH];
 #pragma unroll
-    for (int k = 0; k < VQ_GROUP; ++k) acc[k] = 0.f;
-    const uint32_t c = s_cls[pj];
-    if (!bad && c != 0xFFu) {
-      const uint32_t vm = s_vm[c];
-      const vq_u32x4 st4 = s_start[pj];
-      // pass order = order of the additions (hpp:711); only passes in which some class of this residue has a codebook (wave-uniform)
+    for (int u = 0; u < VQ_BATCH; ++u) {
+#pragma unroll
+      for (int k = 0; k < VQ_GROUP; ++k) acc[u][k] = 0.f;
+      const bool in_range = base + (uint32_t)u * VQ_THREADS + lane < groups;
+      const uint32_t c = in_range && !bad ? (uint32_t)s_cls[pjs[u]] : 0xFFu;
+      cs[u] = c;
+      vms[u] = c != 0xFFu ? (uint32_t)s_vm[c] : 0u;
+    }
+    // pass order = order of the additions (hpp:711); only passes in which some class of this residue has a codebook (wave-uniform).
+    // Within a pass the lane's VQ_BATCH groups are independent: all their table loads are issued before the first one is consumed.
 #pragma unroll 1
-      for (uint32_t pm = X.pass_mask; pm; pm &= pm - 1u) {
-        const uint32_t ps = (uint32_t)__builtin_ctz(pm);
-        if (!((vm >> ps) & 1u)) continue;
+    for (uint32_t pm = X.pass_mask; pm; pm &= pm - 1u) {
+      const uint32_t ps = (uint32_t)__builtin_ctz(pm);
+      const uint32_t pass_base = X.ent_base + (uint32_t)__builtin_amdgcn_readlane((int)X.poff_lanes, (int)ps);
+      float add[VQ_BATCH][VQ_GROUP];
+#pragma unroll
+      for (int u = 0; u < VQ_BATCH; ++u) {
+#pragma unroll
+        for (int k = 0; k < VQ_GROUP; ++k) add[u][k] = 0.f;
+        if (base + (uint32_t)u * VQ_THREADS >= groups) continue;  // wave-uniform
+        if (!((vms[u] >> ps) & 1u)) continue;
+        const uint32_t pj = pjs[u], w0 = w0s[u], c = cs[u];
+        const uint32_t cnt_el = full8 ? (uint32_t)VQ_GROUP : min((uint32_t)VQ_GROUP, X.psize - w0);
         const VqCp cp = s_cp[c * 8u + ps];
-        const uint32_t stw = ps < 4u ? (ps < 2u ? st4[0] : st4[1]) : (ps < 6u ? st4[2] : st4[3]);
-        const uint32_t e0 = X.ent_base + (uint32_t)__builtin_amdgcn_readlane((int)X.poff_lanes, (int)ps) + ((stw >> (16u * (ps & 1u))) & 0xFFFFu);
+        const uint32_t stw = ((const uint32_t*)&s_start[pj])[ps >> 1];
+        const uint32_t e0 = pass_base + ((stw >> (16u * (ps & 1u))) & 0xFFFFu);
         const uint32_t nent1 = cp.inf & 0xFFFFu, sh = (cp.inf >> 16) & 15u;
-        float add[VQ_GROUP];
-        if ((cp.inf & VQ_CP_FAST) && cnt_el == VQ_GROUP) {
-          // The value tables are read through a buffer descriptor over the pool: 32-bit offsets (no 64-bit address arithmetic) and
-          // hardware bounds checking — an out-of-range entry number can only read other table data or, past the pool, zeros; it is
-          // flagged (the packet's values are unspecified then), never dereferenced outside the pool.
-          typedef float vq_f4 __attribute__((ext_vector_type(4)));
-          typedef float vq_f2 __attribute__((ext_vector_type(2)));
-          if (sh >= 3u) {         // one vector covers the group's 8 elements: 8 consecutive components
-            const uint32_t en = entry(e0 + (w0 >> sh));
-            bad_entry |= en > nent1;
-            const uint32_t off = (cp.tab + (en << sh) + (w0 & ((1u << sh) - 1u))) * 4u;
-            const vq_f4 a = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, off, 0, 0));
-            const vq_f4 b = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, off + 16u, 0, 0));
-            add[0] = a.x; add[1] = a.y; add[2] = a.z; add[3] = a.w;
-            add[4] = b.x; add[5] = b.y; add[6] = b.z; add[7] = b.w;
-          } else if (sh == 2u) {  // two vectors of 4
-            const uint32_t i0 = e0 + (w0 >> 2);
-            const uint32_t en0 = entry(i0), en1 = entry(i0 + 1u);
-            bad_entry |= (en0 > nent1) | (en1 > nent1);
-            const vq_f4 a = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, (cp.tab + en0 * 4u) * 4u, 0, 0));
-            const vq_f4 b = __builtin_bit_cast(vq_f4, __builtin_amdgcn_raw_buffer_load_b128(pool, (cp.tab + en1 * 4u) * 4u, 0, 0));
-            add[0] = a.x; add[1] = a.y; add[2] = a.z; add[3] = a.w;
-            add[4] = b.x; add[5] = b.y; add[6] = b.z; add[7] = b.w;
-          } else if (sh == 1u) {  // four vectors of 2
-            const uint32_t i0 = e0 + (w0 >> 1);
-            uint32_t en[4];
+        const bool fast = (X.kinds & VQ_KIND_GEN) == 0u || ((cp.inf & VQ_CP_FAST) && cnt_el == VQ_GROUP);
+        // The value tables are read through a buffer descriptor over the pool: 32-bit offsets (no 64-bit address arithmetic) and
+        // hardware bounds checking — an out-of-range entry number can only read other table data or, past the pool, zeros; it is
+        // flagged (the packet's values are unspecified then), never dereferenced outside the pool.
+        if ((X.kinds & (VQ_KIND_V4 | VQ_KIND_V2)) && fast && sh >= 1u) {
+          // every length >= 2 the same way: four 8-byte reads (a pair of consecutive elements never straddles a vector)
+          const uint32_t dmask = (1u << sh) - 1u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) en[k] = entry(i0 + k);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              bad_entry |= en[k] > nent1;
-              const vq_f2 a = __builtin_bit_cast(vq_f2, __builtin_amdgcn_raw_buffer_load_b64(pool, (cp.tab + en[k] * 2u) * 4u, 0, 0));
-              add[2 * k] = a.x;
-              add[2 * k + 1] = a.y;
-            }
-          } else {                // eight scalars
-            uint32_t en[VQ_GROUP];
-#pragma unroll
-            for (int k = 0; k < VQ_GROUP; ++k) en[k] = entry(e0 + w0 + k);
-#pragma unroll
-            for (int k = 0; k < VQ_GROUP; ++k) {
-              bad_entry |= en[k] > nent1;
-              add[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pool, (cp.tab + en[k]) * 4u, 0, 0));  // (the builtin returns the bits)
-            }
+          for (int m = 0; m < 4; ++m) {
+            const uint32_t w = w0 + 2u * (uint32_t)m;
+            const uint32_t en = entry(e0 + (w >> sh));
+            over |= nent1 - en;
+            const uint32_t idx = cp.tab + (en << sh) + (w & dmask);
+            vq_f2 a;
+            if (TLDS) a = *(const vq_f2*)&s_tab[idx];
+            else a = __builtin_bit_cast(vq_f2, __builtin_amdgcn_raw_buffer_load_b64(pool, idx * 4u, 0, 0));
+            add[u][2 * m] = a.x;
+            add[u][2 * m + 1] = a.y;
           }
-        } else {
+        }
+        if ((X.kinds & VQ_KIND_V1) && fast && sh == 0u) {  // eight scalars
+          uint32_t en[VQ_GROUP];
+#pragma unroll
+          for (int k = 0; k < VQ_GROUP; ++k) en[k] = entry(e0 + w0 + k);
+#pragma unroll
+          for (int k = 0; k < VQ_GROUP; ++k) {
+            over |= nent1 - en[k];
+            if (TLDS) add[u][k] = s_tab[cp.tab + en[k]];
+            else add[u][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pool, (cp.tab + en[k]) * 4u, 0, 0));  // (the builtin returns the bits)
+          }
+        }
+        if ((X.kinds & VQ_KIND_GEN) && !fast) {
           const uint32_t step = s_pp[c * 8u + ps];  // vectors per partition
 #pragma unroll
           for (int k = 0; k < VQ_GROUP; ++k) {
             const uint32_t idx = vq_general_index(X.type, X.psize, w0 + k, step, nent1, cp.tab, e0, ENT_LDS, s_ent + X.ent_shift, eg);
-            bad_entry |= idx == 0xFFFFFFFFu;
-            add[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pool, (idx == 0xFFFFFFFFu ? 0u : idx) * 4u, 0, 0));
+            bad_general |= idx == 0xFFFFFFFFu;
+            add[u][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pool, (idx == 0xFFFFFFFFu ? 0u : idx) * 4u, 0, 0));
           }
         }
-#pragma unroll
-        for (int k = 0; k < VQ_GROUP; ++k) acc[k] += add[k];
       }
+#pragma unroll
+      for (int u = 0; u < VQ_BATCH; ++u)
+#pragma unroll
+        for (int k = 0; k < VQ_GROUP; ++k) acc[u][k] += add[u][k];
     }
     // store (de-interleaving format 2: element e of the interleaved vector is bin e / nch of channel e % nch, hpp:690-692)
-    const uint32_t e_first = X.lim_begin + pc * X.psize + w0;
-    const bool fmt2 = X.type == 2u;
-    if (fmt2 && X.nch == 2u && cnt_el == VQ_GROUP && !(e_first & 1u)) {  // stereo: 4 consecutive bins per channel
-      float* o0 = out + (size_t)X.chan0 * X.n2 + (e_first >> 1);
-      float* o1 = out + (size_t)X.chan1 * X.n2 + (e_first >> 1);
-      if (((uintptr_t)o0 & 15u) == 0 && ((uintptr_t)o1 & 15u) == 0) {
-        *(float4*)o0 = make_float4(acc[0], acc[2], acc[4], acc[6]);
-        *(float4*)o1 = make_float4(acc[1], acc[3], acc[5], acc[7]);
+#pragma unroll
+    for (int u = 0; u < VQ_BATCH; ++u) {
+      if (base + (uint32_t)u * VQ_THREADS + lane >= groups) continue;
+      const uint32_t pj = pjs[u], w0 = w0s[u];
+      uint32_t pc = pj, j = 0;
+      if (X.vch != 1u) {
+        pc = pj / X.vch;
+        j = pj - pc * X.vch;
+      }
+      const uint32_t cnt_el = full8 ? (uint32_t)VQ_GROUP : min((uint32_t)VQ_GROUP, X.psize - w0);
+      const uint32_t e_first = X.lim_begin + pc * X.psize + w0;
+      const bool fmt2 = X.type == 2u;
+      if (fmt2 && X.nch == 2u && cnt_el == VQ_GROUP && !(e_first & 1u)) {  // stereo: 4 consecutive bins per channel
+        float* o0 = out + (size_t)X.chan0 * X.n2 + (e_first >> 1);
+        float* o1 = out + (size_t)X.chan1 * X.n2 + (e_first >> 1);
+        if (((uintptr_t)o0 & 15u) == 0 && ((uintptr_t)o1 & 15u) == 0) {
+          *(float4*)o0 = make_float4(acc[u][0], acc[u][2], acc[u][4], acc[u][6]);
+          *(float4*)o1 = make_float4(acc[u][1], acc[u][3], acc[u][5], acc[u][7]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            o0[k] = acc[u][2 * k];
+            o1[k] = acc[u][2 * k + 1];
+          }
+        }
+      } else if (!fmt2 && cnt_el == VQ_GROUP && (((uintptr_t)(out + (size_t)s_chan[j] * X.n2 + e_first)) & 15u) == 0) {
+        float4* o = (float4*)(out + (size_t)s_chan[j] * X.n2 + e_first);
+        o[0] = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+        o[1] = make_float4(acc[u][4], acc[u][5], acc[u][6], acc[u][7]);
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          o0[k] = acc[2 * k];
-          o1[k] = acc[2 * k + 1];
-        }
+        for (int k = 0; k < VQ_GROUP; ++k)
+          if ((uint32_t)k < cnt_el) {
+            const uint32_t e = e_first + k;
+            if (fmt2) out[(size_t)s_chan[e % X.nch] * X.n2 + e / X.nch] = acc[u][k];
+            else out[(size_t)s_chan[j] * X.n2 + e] = acc[u][k];
+          }
       }
-    } else if (!fmt2 && cnt_el == VQ_GROUP && (((uintptr_t)(out + (size_t)s_chan[j] * X.n2 + e_first)) & 15u) == 0) {
-      float4* o = (float4*)(out + (size_t)s_chan[j] * X.n2 + e_first);
-      o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < VQ_GROUP; ++k)
-        if ((uint32_t)k < cnt_el) {
-          const uint32_t e = e_first + k;
-          if (fmt2) out[(size_t)s_chan[e % X.nch] * X.n2 + e / X.nch] = acc[k];
-          else out[(size_t)s_chan[j] * X.n2 + e] = acc[k];
-        }
-    }
-    pj += q64;
-    wq += r64;
-    if (wq >= X.gpp) {
-      wq -= X.gpp;
-      ++pj;
     }
   }
-  return bad_entry;
+  return bad_general || (int32_t)over < 0;
 }
 
-// grid: as many single-wave workgroups as are resident at once, each walking packets p = blockIdx.x, + gridDim.x, ... (the
-// staged per-residue tables survive from packet to packet while the residue in use stays the same)
-__global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ vqb, uint32_t P,
+// TLDS = false: grid of as many single-wave workgroups as are resident at once, each walking packets p = blockIdx.x, + gridDim.x,
+// ...; value tables read from the pool in global memory (L1/L2 hits).
+// TLDS = true (setups whose tables fit, see vq_build_block): workgroups of several waves that share one copy of the value tables in
+// LDS, staged once at the start; after that barrier each wave walks its packets on its own exactly as above. The accumulate phase
+// then has no vector-memory LOAD left in it — which matters twice: a table row costs an LDS round trip instead of an L1/L2 one, and
+// (vector-memory operations complete in order) no load ever queues behind the previous group's stores.
+// The staged per-residue records survive from packet to packet while the residue in use stays the same.
+template <bool TLDS>
+__global__ void __launch_bounds__(TLDS ? 1024 : VQ_THREADS) vsyn_residue_vq_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ vqb, uint32_t P,
                                                                      const PktInfo* __restrict__ info, const vsyn_vq_packet* __restrict__ vqp,
                                                                      const uint8_t* __restrict__ cls_all, uint64_t num_cls,
                                                                      const uint16_t* __restrict__ ent_all, uint64_t num_ent,
                                                                      float* __restrict__ residue, DevStatus* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_raw0[];
   const ConstHeader* H = hdr_of(cb);
   const VQ_K VqHeader* VH = (const VQ_K VqHeader*)(uintptr_t)vqb;
-  const uint32_t C = H->channels, lane = threadIdx.x;
+  const uint32_t C = H->channels, lane = threadIdx.x & (VQ_THREADS - 1u);
+  const uint32_t wave = TLDS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / VQ_THREADS)) : 0u;
+  const uint32_t waves = TLDS ? blockDim.x / VQ_THREADS : 1u;
   uint32_t lo[7];
-  (void)vq_lds_layout(VH->max_slots, VH->max_classes, lo);
+  const uint32_t wave_bytes = vq_lds_layout(VH->max_slots, VH->max_classes, lo);
+  const uint32_t tab_bytes = TLDS ? vq_align16(VH->img_floats * 4u) : 0u;
+  const float* s_tab = (const float*)s_raw0;
+  if (TLDS) {  // the table image, once per workgroup
+    const vq_u32x4* src = (const vq_u32x4*)(vqb + VH->off_img);
+    for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) ((vq_u32x4*)s_raw0)[i] = src[i];
+    __syncthreads();
+  }
+  uint8_t* const s_raw = s_raw0 + tab_bytes + wave * wave_bytes;
   VqCp* s_cp = (VqCp*)(s_raw + lo[0]);
   uint16_t* s_pp = (uint16_t*)(s_raw + lo[1]);
   vq_u32x4* s_start = (vq_u32x4*)(s_raw + lo[2]);
@@ -297,11 +358,18 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
   const __amdgpu_buffer_rsrc_t pool = __builtin_amdgcn_make_buffer_rsrc((void*)(vqb + VH->off_pool), 0, VH->pool_floats * 4u, 0x00020000);
   const uint32_t max_slots = VH->max_slots;
   uint32_t staged_residue = 0xFFFFFFFFu, staged_map = 0xFFFFFFFFu, staged_sub = 0xFFFFFFFFu;
-  for (uint32_t p = blockIdx.x; p < P; p += gridDim.x) {
-    // wave-uniform descriptors through the scalar cache (the layout kernel / the copies that wrote them finished before this launch)
+#ifdef VQ_STAMPS
+  unsigned long long vq_st[VQ_NSTAMPS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long vq_t = __builtin_amdgcn_s_memtime();
+#endif
+  for (uint32_t p = blockIdx.x * waves + wave; p < P; p += gridDim.x * waves) {
+    // wave-uniform descriptors through the scalar cache (the layout kernel / the copies that wrote them finished before this launch).
+    // (Requesting them a packet ahead does not pay: scalar loads return out of order, so the next LDS wait waits for them too, and
+    // a vector load behind the previous packet's stores completes only after those stores — measured slower.)
     const vq_u32x8 iw = *(const VQ_K vq_u32x8*)(uintptr_t)(info + p);  // PktInfo
     const uint32_t pn = iw[6] & 0xFFFFu, pmapping = iw[7] & 0xFFu, pbad = (iw[7] >> 8) & 0xFFu, pused = iw[4];
     if (pbad || pn == 0) continue;  // flagged by the layout kernel; nothing downstream reads this packet's residue
+    VQ_STAMP(0);  // PktInfo arrived
     const uint32_t n2 = pn / 2u;
     const vq_u32x4 vw = *(const VQ_K vq_u32x4*)(uintptr_t)(vqp + p);   // vsyn_vq_packet
     const uint64_t entry_off = (uint64_t)vw[0] | ((uint64_t)vw[1] << 32);
@@ -326,6 +394,7 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
                                            (__attribute__((address_space(3))) void*)(s_ent + c0 * 8u), 16, 0, 0);
     }
 
+    VQ_STAMP(1);  // vsyn_vq_packet arrived, entry staging issued
     const uint32_t num_submaps = mp->num_submaps;
     for (uint32_t s = 0; s < num_submaps; ++s) {
       const uint32_t nch = mp->sub_nch[s];
@@ -337,6 +406,7 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
       X.type = rw[0];
       X.psize = rw[3];
       X.pass_mask = rw[6];
+      X.kinds = rw[7];
       const uint32_t nclass = rw[4];
       const bool fmt2 = X.type == 2u;
       X.nch = nch;
@@ -372,7 +442,7 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
           if (book >= 0) {
             const VqBook bk = books[book];
             per_part = X.psize / bk.dims;
-            e.tab = bk.table_off;
+            e.tab = TLDS ? bk.lds_off : bk.table_off;
             e.inf = (bk.entries - 1u) & 0xFFFFu;
             if (X.type != 0u && (bk.dims & (bk.dims - 1u)) == 0u) e.inf |= VQ_CP_FAST | ((31u - (uint32_t)__clz((int)bk.dims)) << 16);
           }
@@ -386,6 +456,7 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
         }
         staged_residue = rid;
       }
+      VQ_STAMP(2);  // submap / residue facts
       const uint8_t* cls = cls_all + cls_cur;
       if ((uint64_t)cls_cur + (uint64_t)X.npj > num_cls || 8u * X.npj > max_slots) bad = true;
       asm volatile("" ::: "memory");
@@ -440,15 +511,18 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
         if (lane == (uint32_t)ps) X.poff_lanes = run;
         run += (carry[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
       }
+      VQ_STAMP(3);  // classifications read, scan
       const uint32_t sub_entries = bad ? 0u : run;
       if ((uint64_t)ent_cur + sub_entries > pkt_entries) bad = true;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the entries have landed in s_ent
+      VQ_STAMP(4);  // wait for the entries (and for the previous packet's stores)
 
       // ---- accumulate + store ----
       bool bad_entry;
-      if (ent_lds) bad_entry = vq_accumulate<true>(X, lane, bad, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
-      else bad_entry = vq_accumulate<false>(X, lane, bad, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, out);
+      if (ent_lds) bad_entry = vq_accumulate<true, TLDS>(X, lane, bad, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, s_tab, out);
+      else bad_entry = vq_accumulate<false, TLDS>(X, lane, bad, s_cp, s_pp, s_start, s_ent, s_vm, s_cls, s_chan, ent, pool, s_tab, out);
       if (bad_entry) raise_status(status, VSYN_ST_BAD_VQ, p);
+      VQ_STAMP(5);  // accumulate + stores issued
 
       // elements outside the partitions stay zero (hpp:1186-1190): [0, lim_begin) and [lim_begin + parts * psize, len) of every
       // vector; per channel these are two runs of consecutive bins (format 2: element e is bin e / nch of channel e % nch)
@@ -462,10 +536,18 @@ __global__ void __launch_bounds__(VQ_THREADS) vsyn_residue_vq_kernel(const uint8
       }
       cls_cur += X.npj;
       ent_cur += sub_entries;
+      VQ_STAMP(6);  // zero fill issued
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a packet without submaps: the entry loads must not outlive s_ent's reuse)
     if (lane == 0 && (bad || ent_cur != pkt_entries)) raise_status(status, VSYN_ST_BAD_VQ, p);  // count must match the classifications
+#ifdef VQ_STAMPS
+    vq_st[VQ_NSTAMPS - 1] += 1;
+#endif
   }
+#ifdef VQ_STAMPS
+  if (lane == 0 && blockIdx.x * waves + wave < 8192)
+    for (int i = 0; i < VQ_NSTAMPS; ++i) g_vq_stamps[blockIdx.x * waves + wave][i] = vq_st[i];
+#endif
 }
 #endif  // __HIPCC__
 
@@ -489,7 +571,7 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
     books[i].dims = b.dimensions;
     books[i].entries = b.num_entries;
     books[i].table_off = 0xFFFFFFFFu;
-    books[i].pad = 0;
+    books[i].lds_off = 0xFFFFFFFFu;
     if (b.lookup) {
       if (b.dimensions == 0 || b.dimensions > 65535u) return "vq setup: codebook " + std::to_string(i) + " has a bad vector length";
       if (b.num_entries == 0 || b.num_entries > 65536u) return "vq setup: codebook " + std::to_string(i) + " has more than 65536 entries";
@@ -523,7 +605,35 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
       if (r.partition_size % books[b].dims) return "vq setup: vector length of codebook " + std::to_string(b) + " does not divide the partition size";
       d.books[k] = (int16_t)b;
       d.pass_mask |= 1u << (k & 7u);
+      const uint32_t dm = books[b].dims;
+      if (r.type == 0 || (dm & (dm - 1u)) || (r.partition_size & (VQ_GROUP - 1u))) d.kinds |= 8u;  // VQ_KIND_GEN (partition tails too)
+      if (r.type != 0 && !(dm & (dm - 1u))) d.kinds |= dm >= 4u ? 1u : (dm == 2u ? 2u : 4u);  // VQ_KIND_V4 / V2 / V1
     }
+  }
+  // The LDS table image: every table some residue uses, as it is. A setup is eligible for the LDS-table kernel if the image fits
+  // VQ_IMG_MAX_BYTES and no residue needs the general route. (Measured and dropped: storing the big lattice books libvorbis writes —
+  // value k a function of digit k of the entry number, e.g. the stereo fixture's 8 x 6561 table of 205 KB — as half vectors indexed
+  // by entry % cq and entry / cq makes every real setup fit, bit-exactly, but the index arithmetic costs more than the L2 gathers it
+  // replaces: 0.207 ms against 0.193 ms with the pool in global memory.)
+  std::vector<float> img;
+  bool img_ok = true;
+  {
+    std::vector<uint8_t> used(vq->num_codebooks, 0);
+    for (const VqResidue& r : residues) {
+      if (r.kinds & 8u) img_ok = false;  // VQ_KIND_GEN
+      for (uint32_t k = 0; k < r.nclass * 8u; ++k)
+        if (r.books[k] >= 0) used[r.books[k]] = 1;
+    }
+    for (uint32_t i = 0; i < vq->num_codebooks && img_ok; ++i) {
+      if (!used[i]) continue;
+      const vsyn_codebook& b = vq->codebooks[i];
+      while (img.size() & 3u) img.push_back(0.f);
+      books[i].lds_off = (uint32_t)img.size();
+      if (((size_t)b.dimensions * b.num_entries + img.size()) * 4u > VQ_IMG_MAX_BYTES) img_ok = false;
+      else img.insert(img.end(), b.lookup, b.lookup + (size_t)b.dimensions * b.num_entries);
+    }
+    if (!img_ok) img.clear();
+    while (img.size() & 3u) img.push_back(0.f);
   }
   std::vector<VqMap> maps(vq->num_mappings);
   const uint32_t n2max = H.bs[1] / 2u;
@@ -576,6 +686,9 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
   vh.off_pool = (uint32_t)off;
   vh.pool_floats = (uint32_t)pool.size();
   off = align16(off + pool.size() * sizeof(float) + 16);
+  vh.off_img = (uint32_t)off;
+  vh.img_floats = (uint32_t)img.size();
+  off = align16(off + img.size() * sizeof(float));
   vh.total_bytes = (uint32_t)off;
   block.assign(off, 0);
   memcpy(block.data(), &vh, sizeof(vh));
@@ -583,5 +696,6 @@ static inline std::string vq_build_block(const vsyn_vq_setup* vq, const ConstHea
   memcpy(block.data() + vh.off_residues, residues.data(), residues.size() * sizeof(VqResidue));
   memcpy(block.data() + vh.off_maps, maps.data(), maps.size() * sizeof(VqMap));
   if (!pool.empty()) memcpy(block.data() + vh.off_pool, pool.data(), pool.size() * sizeof(float));
+  if (!img.empty()) memcpy(block.data() + vh.off_img, img.data(), img.size() * sizeof(float));
   return std::string();
 }
