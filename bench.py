@@ -158,7 +158,7 @@ def run_config5(args, rank, world, local, device):
     n = args.files_per_gpu
     cores = os.cpu_count() or 16
     share = max(2, min(16, cores // max(1, world)))   # this rank's cores: one entropy worker each; the feeders mostly wait on the GPU
-    feeders = 3 if share >= 12 else (2 if share >= 6 else 1)
+    feeders = args.feeders or (3 if share >= 12 else (2 if share >= 6 else 1))
     threads = args.host_threads or share
     datas = (C.c_char_p * n)(*([blob] * n))
     lens = (C.c_size_t * n)(*([len(blob)] * n))
@@ -206,9 +206,14 @@ def run_config5(args, rank, world, local, device):
                            "parallelism": "files sharded over %d GPU(s), no data-path collective" % world},
                 # end to end this workload is bound by the host's entropy decode (the GPU is busy a few % of the time): no kernel
                 # roofline applies; the kernel workloads carry those
+                # end to end this workload is bound outside the kernels (the GPU is busy a few % of the time): the host's entropy decode
+                # (entropy_cpu_s_per_step / threads of the step) and the PCIe copy of the decoded PCM back to the host; no kernel
+                # roofline applies, the kernel workloads carry those
                 "roofline": {"bound": "host", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                             "note": "host entropy decode (Ogg paging + Huffman/VQ bit parse) bounds the pipeline; packets/s per entropy "
-                                     "thread = %.0f" % (total * args.steps / dt / max(1, threads * world))},
+                             "note": "host entropy decode (Ogg paging + Huffman/VQ bit parse: %.0f packets/s per entropy thread while it runs) and the "
+                                     "PCM copy to the host (%.1f GB/s device-to-host%s) bound the pipeline" % (
+                                         total / max(extra[0], 1e-9), extra[2] * 2 * (2 if args.pcm_s16 else 4) * args.steps / dt / 1e9,  # (the fixture is stereo)
+                                         ", int16" if args.pcm_s16 else ", f32")},
                 "cpu_baseline": cpu,
                 "packets_per_s_per_host_thread": round(total * args.steps / dt / max(1, threads * world), 1),
                 "realtime_factor": round(extra[2] * args.steps / dt / 44100.0, 1),
@@ -232,6 +237,7 @@ def main():
                          "config5: real .ogg files end to end (host entropy threads + GPU), files sharded over the ranks; use few steps, "
                          "e.g. --steps 3 --warmup 1 (one step = one pass over the rank's files)")
     ap.add_argument("--files-per-gpu", type=int, default=10640, help="config5: replicas of the stereo fixture per rank (94 audio packets each)")
+    ap.add_argument("--feeders", type=int, default=0, help="config5: feeder threads per rank (pack, GPU call, deliver; 0: 3 on a 16-core share)")
     ap.add_argument("--host-threads", type=int, default=0, help="config5: entropy worker threads per rank (0: this rank's share of the cores, at most 16)")
     ap.add_argument("--blocksizes", default="256,2048", help="config3/config4 with another blocksize pair, e.g. 128,1024 (diagnostic: the "
                                                              "headline configurations are 256/2048)")

@@ -443,7 +443,7 @@ void vsyn_destroy(vsyn_handle* h) {
       }
       if (pk) {
         static const char* nm[VSYN_NSTAMPS - 1] = {"loop", "residue+handoff+couple", "loads+floor setup", "floor product", "mirror+pre-rot", "partner wait 2",
-                                                   "fft512", "post+window+overlap", "stores"};
+                                                   "fft512", "post+window+overlap", "stores / short pass: stores", "short: descriptors", "short: rows", "short: couple+floor", "short: fft+window", "-", "-"};
         double tot = 0;
         for (int i = 0; i + 1 < VSYN_NSTAMPS; ++i) tot += sum[i];
         fprintf(stderr, "vsyn stamps: %llu waves, %llu wave-packets, %.0f cycles per wave-packet\n", waves, pk, tot / pk);

@@ -39,7 +39,7 @@
 // wave's LDS queue there: phases no longer overlap each other, so the sum exceeds the unstamped iteration). Read back and
 // printed by vsyn_destroy. Diagnostic builds only.
 #ifdef VSYN_STAMPS
-#define VSYN_NSTAMPS 10
+#define VSYN_NSTAMPS 16
 __device__ unsigned long long g_vsyn_stamps[8192][VSYN_NSTAMPS];
 #define STAMP(i)                                                  \
   do {                                                            \
@@ -418,7 +418,11 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
                                                      const vsyn_segment sg, const SegInfo si, const uint32_t q, const uint32_t qa, const uint32_t qb,
                                                      const uint32_t C, const uint32_t c, float* plane, const PktInfo* ip, const uint32_t epoch,
                                                      const uint32_t prev_kind, const uint32_t prev_half, float (&P)[8], const uint32_t bseg0,
-                                                     const uint32_t sidx, const uint32_t xsl, const uint32_t posts, const uint32_t ys_stride, bool& hand_over_out) {
+                                                     const uint32_t sidx, const uint32_t xsl, const uint32_t posts, const uint32_t ys_stride, bool& hand_over_out
+#ifdef VSYN_STAMPS
+                                                     , unsigned long long (&st_acc)[VSYN_NSTAMPS], unsigned long long& st_last
+#endif
+                                                     ) {
   constexpr uint32_t MS = 128u, ML = 1024u;
   const ConstHeader* H = hdr_of(A.cb);
   // ---- the pass: packets q .. q+Jp-1 (lane j < 8 holds the descriptor of packet q + j) ----------------------------------------------
@@ -430,6 +434,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
   const bool cand = lane < 8u && q + lane < qb;
   const uint64_t okm = __ballot(cand && !((db[3] >> 8) & 0xFFu) && !((db[2] >> 16) & 0xFFu) && (db[3] & 0xFFu) == map0);
   const uint32_t Jp = (uint32_t)__builtin_ctzll(~okm);  // >= 1: the caller saw a valid short block at q
+  STAMP(9);   // short pass: descriptors arrived
   const uint32_t qn = q + Jp, p0 = sg.first_packet + q;
   const uint32_t emit_l = q + (lane & 7u) < qa ? 0u : da[3];  // the halo emits nothing
   // ---- loads -------------------------------------------------------------------------------------------------------------------------
@@ -450,6 +455,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
   if (ROLE != 0) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
+    STAMP(10);  // short pass: rows arrived, written to the exchange image
     pair_post(&my_flags[0], epoch);
     pair_wait(&partner_flags[0], epoch);
 #pragma unroll
@@ -527,6 +533,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
       }
     }
   }
+  STAMP(11);  // short pass: coupling (partner waits), floor set-up and product
   // ---- IMDCT x 8 ------------------------------------------------------------------------------------------------------------------------
   float2 z[8];
   {
@@ -604,6 +611,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
     }
     hand_over = !nbad && nlng;
   }
+  STAMP(12);  // short pass: FFT, post-rotation, window reads
   vmem_drain();  // loads only are in flight: finish them before the PCM stores (see vmem_drain)
   float oh_s[4], oh_m[4], n_s[4], n_m[4];
   const int mirror = (int)(lane ^ 7u);
@@ -781,7 +789,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   uint32_t lane_v = lane0;
   vmem_drain();  // see vmem_drain(): the loop must not inherit "the residue registers were loaded last" from here
 #ifdef VSYN_STAMPS
-  unsigned long long st_acc[VSYN_NSTAMPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_acc[VSYN_NSTAMPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_readcyclecounter();
 #endif
   // The two waves of a coupled channel pair (adjacent waves, same run, same packets) each load ONLY their own channel
@@ -838,7 +846,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
       }
       bool ho = false;
       const uint32_t Jp = fused_short_pass<ROLE, TAPC>(A, T, xb, pxb, (float2*)seg, cbuf, my_flags, partner_flags, lane, sg, si, q, qa, qb, C, c, plane, ip, it + 1u,
-                                                 prev_kind, prev_half, P, bseg[0], sidx, xsl, posts, ys_stride, ho);
+                                                 prev_kind, prev_half, P, bseg[0], sidx, xsl, posts, ys_stride, ho
+#ifdef VSYN_STAMPS
+                                                 , st_acc, st_last
+#endif
+                                                 );
       prev_kind = ho ? K_LDS : K_REG;
       prev_half = 128u;
       prev_next_long = 0u;

@@ -430,6 +430,42 @@ OkOrError VorbisResidue::decode(BitReader& reader, const std::vector<VorbisCodeb
 }
 
 // Same control flow as decode() above with the table look-up and the adds left out: what remains is the bit-serial half.
+void VorbisResidue::prepare(const std::vector<VorbisCodebook>& codebooks) {
+  runs.assign((size_t)num_classifications * 8, Run());
+  for (size_t k = 0; k < runs.size() && k < books.size(); ++k) {
+    const int b = books[k];
+    if (b < 0 || (size_t)b >= codebooks.size()) continue;
+    const VorbisCodebook& vq = codebooks[(size_t)b];
+    if (!vq.dimensions_ || vq.fast_.empty()) continue;
+    runs[k].fast = vq.fast_.data();
+    runs[k].book = &vq;
+    runs[k].count = partition_size / vq.dimensions_;
+    runs[k].num_entries = vq.num_entries_;
+  }
+  cls_unpack.clear();
+  if (classbook < codebooks.size() && num_classifications) {
+    const VorbisCodebook& cb = codebooks[classbook];
+    if (cb.dimensions_ >= 1 && cb.dimensions_ <= 4 && cb.num_entries_ <= 65536) {
+      cls_unpack.resize(cb.num_entries_);
+      for (uint32_t w = 0; w < cb.num_entries_; ++w) {
+        uint32_t temp = w, packed = 0;
+        for (uint32_t i = cb.dimensions_; i > 0; --i) {  // hpp:717-721: the LAST partition of the group takes temp % classes
+          packed |= (temp % num_classifications) << (8 * (i - 1));
+          temp /= num_classifications;
+        }
+        cls_unpack[w] = packed;
+      }
+    }
+  }
+}
+
+// The bit-serial half of VorbisResidue::decode (hpp:696-760) and nothing else: class words and codebook entry numbers, in decode
+// order. This is where the host front-end spends its time, so the loop keeps the bit window in registers across code words AND
+// across codebooks (a 64-bit buffer refilled by one unaligned load when fewer than kFastBits bits are left; VorbisCodebook::
+// decodeRun reloaded it per run of ~9 words), reads what a (class, pass) pair means from a table built at setup time (no
+// division, no codebook look-up per partition) and writes through a cursor into storage grown geometrically (the per-run
+// vector::resize was 12 % of the profile). Code words longer than the prefix table, and the last 16 bytes of a packet, go through
+// VorbisCodebook::decodeScalar on the BitReader.
 OkOrError VorbisResidue::decode_entries(BitReader& reader, const std::vector<VorbisCodebook>& codebooks, uint32_t num_channel,
                                         const std::vector<bool>& channel_used, uint32_t decode_len, std::vector<uint8_t>& cls_out,
                                         std::vector<uint16_t>& entries_out, int type_override) const {
@@ -445,43 +481,129 @@ OkOrError VorbisResidue::decode_entries(BitReader& reader, const std::vector<Vor
   const uint32_t cw = cbook.dimensions_;
   const uint32_t n_to_read = lim_end - lim_begin;
   if (!n_to_read) return OkOrError();
+  CHECK(runs.size() == (size_t)num_classifications * 8);  // prepare() ran
   const uint32_t parts = n_to_read / partition_size;
+  CHECK(lim_begin + parts * partition_size <= decode_len);
   const uint32_t per_ch = parts + cw;
   static thread_local std::vector<uint8_t> cls;  // (scratch: one decoder per thread, Callbacks.h:16-21)
   cls.assign((size_t)num_channel * per_ch, 0);
   uint32_t pass_mask = 0;  // passes in which some class has a codebook: the others read nothing and are skipped whole
   for (uint32_t x : cascades) pass_mask |= x;
-  for (int pass = 0; pass < 8; ++pass) {
+
+  // ---- bit window ----
+  const uint8_t* const p = reader.p_;
+  const size_t len = reader.len_;
+  const size_t fast_end = len >= 16 ? (len - 16) * 8 : 0;  // bit positions up to here may refill with an 8-byte load
+  size_t pos = reader.byte_ * 8 + (size_t)reader.bit_;
+  uint64_t buf = 0;
+  int have = 0;
+  const uint32_t fmask = (1u << kFastBits) - 1u;
+  const uint32_t* const cfast = cbook.fast_.data();
+  // one code word of `book` (prefix table `fast`); 0xffffffff: no such code word
+  auto word = [&](const uint32_t* fast, const VorbisCodebook& book) -> uint32_t {
+    if (have < kFastBits) {
+      if (len >= 16 && pos <= fast_end) {
+        memcpy(&buf, p + (pos >> 3), 8);
+        buf >>= (pos & 7);
+        have = 64 - (int)(pos & 7);
+      } else {
+        have = 0;
+      }
+    }
+    if (have >= kFastBits) {
+      const uint32_t e = fast[(uint32_t)buf & fmask];
+      if (e) {
+        const int l = (int)(e & 0xffu);
+        buf >>= l;
+        have -= l;
+        pos += (size_t)l;
+        return e >> 8;
+      }
+    }
+    reader.byte_ = pos >> 3;  // the tree walk (or the tail of the packet): through the reader
+    reader.bit_ = (int)(pos & 7);
+    const uint32_t v = book.decodeScalar(reader);
+    pos = reader.byte_ * 8 + (size_t)reader.bit_;
+    have = 0;
+    return v;
+  };
+
+  // ---- output cursor ----
+  size_t at = entries_out.size();
+  auto room = [&](size_t need) {
+    if (at + need > entries_out.size()) entries_out.resize(at + need + 2048);  // (the vector's own growth policy keeps this amortised)
+  };
+  bool bad_word = false;
+  const bool unpack = !cls_unpack.empty();
+  for (int pass = 0; pass < 8 && !bad_word; ++pass) {
     if (pass > 0 && !((pass_mask >> pass) & 1u)) continue;
     uint32_t pc = 0;
-    while (pc < parts) {
+    while (pc < parts && !bad_word) {
       if (pass == 0)
         for (uint32_t j = 0; j < num_channel; ++j) {
           if (!channel_used[j]) continue;
-          uint32_t temp = cbook.decodeScalar(reader);
-          for (uint32_t i = cw; i > 0; --i) {
-            cls[(size_t)j * per_ch + (i - 1) + pc] = (uint8_t)(temp % num_classifications);
-            temp /= num_classifications;
+          uint32_t temp = word(cfast, cbook);
+          uint8_t* row = &cls[(size_t)j * per_ch + pc];
+          if (unpack && temp < cls_unpack.size()) {
+            const uint32_t packed = cls_unpack[temp];
+            for (uint32_t i = 0; i < cw; ++i) row[i] = (uint8_t)(packed >> (8 * i));
+          } else {
+            for (uint32_t i = cw; i > 0; --i) {
+              row[i - 1] = (uint8_t)(temp % num_classifications);
+              temp /= num_classifications;
+            }
           }
         }
       for (uint32_t i = 0; i < cw && pc < parts; ++i, ++pc) {
         for (uint32_t j = 0; j < num_channel; ++j) {
           if (!channel_used[j]) continue;
-          const int book = books[(size_t)cls[(size_t)j * per_ch + pc] * 8 + (size_t)pass];
-          if (book < 0) continue;
-          const VorbisCodebook& vq = codebooks[(size_t)book];
-          CHECK(vq.lookup_type_ != 0);  // decodeVector on a scalar-only book
-          const uint32_t count = partition_size / vq.dimensions_;  // stream_can_use_vq: dimensions_ divides partition_size
-          CHECK(lim_begin + (pc + 1) * partition_size <= decode_len);
-          const size_t at = entries_out.size();
-          entries_out.resize(at + count);
-          uint16_t* dst = &entries_out[at];
-          const uint32_t worst = vq.decodeRun(reader, count, dst);
-          CHECK(worst < vq.num_entries_);  // (0xffffffff = no such code word)
+          const Run& R = runs[(size_t)cls[(size_t)j * per_ch + pc] * 8 + (size_t)pass];
+          if (!R.fast) continue;
+          CHECK(R.book->lookup_type_ != 0);  // decodeVector on a scalar-only book
+          room(R.count);
+          uint16_t* dst = entries_out.data() + at;
+          uint32_t worst = 0, k = 0;
+          const uint32_t* const fast = R.fast;
+          const uint32_t count = R.count;
+          have = 0;  // (the run loop below works on its own copy of the window)
+          while (k < count) {
+            if (len >= 16 && pos <= fast_end) {
+              uint64_t w;
+              memcpy(&w, p + (pos >> 3), 8);
+              w >>= (pos & 7);
+              const int avail = 64 - (int)(pos & 7);
+              int used = 0;
+              bool slow = false;
+              while (k < count && avail - used >= kFastBits) {
+                const uint32_t e = fast[(uint32_t)w & fmask];
+                if (!e) {  // longer than the table covers (or not a code word): the tree walk decides
+                  slow = true;
+                  break;
+                }
+                const int l = (int)(e & 0xffu);
+                w >>= l;
+                used += l;
+                const uint32_t v = e >> 8;
+                worst = v > worst ? v : worst;
+                dst[k++] = (uint16_t)v;
+              }
+              pos += (size_t)used;
+              if (!slow) continue;
+            }
+            const uint32_t v = word(fast, *R.book);  // (with have == 0 and a code word the table does not hold: through the reader)
+            worst = v > worst ? v : worst;
+            dst[k++] = (uint16_t)v;
+          }
+          at += R.count;
+          if (worst >= R.num_entries) bad_word = true;  // (0xffffffff = no such code word)
         }
       }
     }
   }
+  reader.byte_ = pos >> 3;
+  reader.bit_ = (int)(pos & 7);
+  entries_out.resize(at);
+  CHECK(!bad_word);
   for (uint32_t j = 0; j < num_channel; ++j) cls_out.insert(cls_out.end(), cls.begin() + (size_t)j * per_ch, cls.begin() + (size_t)j * per_ch + parts);
   return OkOrError();
 }
@@ -559,6 +681,7 @@ OkOrError VorbisStreamSetup::parse(BitReader& reader, const VorbisIdHeader& head
   const size_t left = reader.bitsLeft();
   CHECK(left < 8);
   if (left) CHECK(reader.readBits<uint32_t>((int)left) == 0);
+  for (VorbisResidue& r : residues) r.prepare(codebooks);
   return OkOrError();
 }
 

@@ -104,6 +104,16 @@ struct VorbisResidue {  // Vorbis I 8.6
   uint8_t num_classifications = 0, classbook = 0;
   std::vector<uint32_t> cascades;
   std::vector<int16_t> books;  // [class][pass], -1 = none
+  // decode_entries' view of `books` (built by prepare() once the codebooks are parsed; the pointers go into the setup's shared
+  // codebook vector): per (class, pass) the prefix table, how many code words a partition holds and the entry count
+  struct Run {
+    const uint32_t* fast = nullptr;  // nullptr: no codebook in this pass
+    const VorbisCodebook* book = nullptr;
+    uint32_t count = 0, num_entries = 0;
+  };
+  std::vector<Run> runs;             // [class][pass]
+  std::vector<uint32_t> cls_unpack;  // class word -> its <= 4 class numbers, 8 bits each, first partition lowest (empty: computed per word)
+  void prepare(const std::vector<VorbisCodebook>& codebooks);
   OkOrError parse(BitReader& reader, int num_codebooks);
   // out: num_channel vectors of decode_len floats, zero-initialised by the caller; adds the VQ vectors (8.6.2-8.6.5)
   OkOrError decode(BitReader& reader, const std::vector<VorbisCodebook>& codebooks, uint32_t num_channel, const std::vector<bool>& channel_used,
@@ -133,8 +143,26 @@ struct VorbisModeNumber {
   OkOrError parse(BitReader& reader, int num_mappings, const VorbisIdHeader& header);
 };
 
+// A vector whose copies share the elements: the parsed codebooks (decode trees, prefix tables, VQ value tables — hundreds of KB)
+// never change once VorbisStreamSetup::parse has returned, so a stream that takes its setup from the SetupCache shares them with
+// every other stream of that setup instead of copying them (copying cost ~8 % of entropy-decoding a two-second file).
+template <typename T>
+struct SharedVec {
+  std::shared_ptr<std::vector<T>> v = std::make_shared<std::vector<T>>();
+  size_t size() const { return v->size(); }
+  bool empty() const { return v->empty(); }
+  const T& operator[](size_t i) const { return (*v)[i]; }
+  T& operator[](size_t i) { return (*v)[i]; }
+  void resize(size_t n) { v = std::make_shared<std::vector<T>>(n); }  // (a fresh vector: other holders keep theirs)
+  typename std::vector<T>::iterator begin() { return v->begin(); }
+  typename std::vector<T>::iterator end() { return v->end(); }
+  typename std::vector<T>::const_iterator begin() const { return v->begin(); }
+  typename std::vector<T>::const_iterator end() const { return v->end(); }
+  operator const std::vector<T>&() const { return *v; }
+};
+
 struct VorbisStreamSetup {
-  std::vector<VorbisCodebook> codebooks;
+  SharedVec<VorbisCodebook> codebooks;
   std::vector<VorbisFloor> floors;
   std::vector<VorbisResidue> residues;
   std::vector<VorbisMapping> mappings;
