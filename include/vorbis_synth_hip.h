@@ -159,8 +159,9 @@ void vsyn_destroy(vsyn_handle* h);
 uint32_t vsyn_ys_stride(const vsyn_handle* h);           /* uint16 elements per (packet,channel) row of ys */
 uint32_t vsyn_channels(const vsyn_handle* h);
 /* Which synthesis kernels this handle's setup gets (diagnostics, tests): bit 0 = the fused kernel takes runs of long blocks,
- * bit 1 = it also takes mixed-block runs and carry-ins; 0 = every batch goes through the staged (any-shape) kernels.
- * Results are the same either way; only the speed differs. */
+ * bit 1 = it also takes mixed-block runs and carry-ins; neither = every batch goes through the staged (any-shape) kernels.
+ * Bit 8 (after vsyn_attach_vq) = the residue VQ kernel keeps the attached setup's value tables in LDS (they fit) instead of
+ * gathering them from global memory. Results are the same either way; only the speed differs. */
 uint32_t vsyn_fused_paths(const vsyn_handle* h);
 /* size in bytes of the constant block, and a copy of it (for the one RCCL broadcast of a multi-GPU job) */
 size_t vsyn_const_block_bytes(const vsyn_handle* h);

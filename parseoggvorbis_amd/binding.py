@@ -312,6 +312,7 @@ class Synth:
         rc = self.lib.vsyn_attach_vq(self.h, C.byref(self._vq), C.byref(err))
         if rc != VSYN_OK:
             raise VsynError(rc, (err.value or b"").decode())
+        self.fused_paths = self.lib.vsyn_fused_paths(self.h)  # (+ bit 8: the VQ kernel keeps this setup's value tables in LDS)
 
     def submit_host_vq(self, packets, segments, ys, vq_packets, cls, entries, residue_floats, plane_stride,
                        want_residue=True, flags=0):

@@ -486,7 +486,7 @@ void vsyn_destroy(vsyn_handle* h) {
 
 uint32_t vsyn_ys_stride(const vsyn_handle* h) { return h ? h->H.ys_stride : 0; }
 uint32_t vsyn_channels(const vsyn_handle* h) { return h ? h->H.channels : 0; }
-uint32_t vsyn_fused_paths(const vsyn_handle* h) { return h ? h->fused_mask : 0; }
+uint32_t vsyn_fused_paths(const vsyn_handle* h) { return h ? (h->fused_mask | (h->vq_tables_in_lds ? 0x100u : 0u)) : 0; }
 size_t vsyn_const_block_bytes(const vsyn_handle* h) { return h ? h->host_const.size() : 0; }
 
 int vsyn_profile_enable(vsyn_handle* h, int on) {

@@ -128,6 +128,28 @@ def test_vq_stage_matches_oracle_on_random_entries(probe, name, pattern, tmp_pat
     assert np.array_equal(out["residue"].view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("tables_in_lds", [True, False])
+def test_vq_stage_tables_in_lds_and_in_global_memory(tables_in_lds, monkeypatch):
+    """The two ways the VQ kernel reads codebook value tables — one copy per workgroup in LDS when the setup's tables fit (the
+    synthetic setup: 15 KB; workgroups of several waves), or gathered from global memory (every setup with a large lattice book, e.g.
+    the stereo fixture's 205 KB table; here forced with VSYN_VQ_NO_LDS_TABLES=1) — rebuild the same residue, bit for bit the
+    oracle's, on long and short blocks with partially unused channels. Which way ran is asserted (vsyn_fused_paths bit 8)."""
+    from tests.workloads import fixture_like_spec, synthetic_vq_spec
+    if not tables_in_lds:
+        monkeypatch.setenv("VSYN_VQ_NO_LDS_TABLES", "1")
+    spec = fixture_like_spec(2)
+    vqs = synthetic_vq_spec(2, spec.blocksize1)
+    pk, seg, vqp, cls, ent, want = _random_vq_batch(spec, vqs, 40, 12, [1, 1, 0, 1, 0, 0], seed=33)
+    syn = Synth(spec, max_streams=40)
+    syn.attach_vq(vqs)
+    assert bool(syn.fused_paths & 0x100) == tables_in_lds, hex(syn.fused_paths)
+    ys = np.zeros((len(pk), 2, syn.ys_stride), np.uint16)
+    out = syn.submit_host_vq(pk, seg, ys, vqp, cls, ent, want.size, 12 * spec.blocksize1 // 2)
+    assert out["rc"] == 0, out
+    assert np.array_equal(out["residue"].view(np.uint32), want.view(np.uint32))
+    assert np.abs(want).max() > 0
+
+
 @pytest.mark.parametrize("variant", ["format0", "format1x2", "submaps"])
 def test_vq_stage_other_residue_formats(variant):
     """Residue formats / shapes the fixtures do not have (format 0, two format-1 vectors in one submap with unused channels,

@@ -4,7 +4,9 @@
 TAG=${1:-r02_z}
 mkdir -p gpurun_out
 bash tools/profile_round.sh $TAG > gpurun_out/$TAG.log 2>&1
-echo "profile_round done" 
+echo "profile_round done"
+BENCH_ARGS="--workload config3_vq" bash tools/profile_round.sh ${TAG}_vq > gpurun_out/${TAG}_vq.log 2>&1
+echo "vq profile_round done"
 B="timeout -k 10 400 python bench.py"
 ( $B --steps 20 --warmup 5 ;
   $B --steps 20 --warmup 5 --no-cpu-baseline ;
@@ -32,5 +34,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_u1024 -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --blocksizes 128,1024 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_u1024.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/${TAG}_p200 gpurun_out/${TAG}_noov gpurun_out/${TAG}_u1024 -name "*kernel_stats.csv" | while read f; do cp $f gpurun_out/$(echo $f | cut -d/ -f2)_kernel_stats.csv; done
-rm -rf gpurun_out/${TAG}_p200 gpurun_out/${TAG}_noov gpurun_out/${TAG}_u1024 gpurun_out/$TAG/pmc*/ gpurun_out/$TAG/stats/
+rm -rf gpurun_out/${TAG}_p200 gpurun_out/${TAG}_noov gpurun_out/${TAG}_u1024 gpurun_out/$TAG/pmc*/ gpurun_out/$TAG/stats/ gpurun_out/${TAG}_vq/pmc*/ gpurun_out/${TAG}_vq/stats/
 ls gpurun_out | grep $TAG
