@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="diagnostic builds only (VSYN_KNOCKOUT): do not gate on the oracle spot check")
     ap.add_argument("--staged", action="store_true", help="time the staged kernels instead of the fused one")
+    ap.add_argument("--no-steady", action="store_true", help="skip the longer run reported as steady_state beside a short timed region")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no HIP events around the dominant kernel (roofline.achieved is then null)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -424,6 +425,23 @@ def main():
 
     dt, total_units, _ = sharding.aggregate(dt, units, device)  # max clock over ranks, summed packet count
 
+    # Beside the contract's number: the same step over a longer stretch, timed right after it. A short run that starts on an idle
+    # GPU sits in a clock-management transient (2-3 ms after the first launch the kernels run 5-10 % slower for ~5 ms:
+    # profiles/r02_experiments/step_anatomy_kernel_trace.txt), so K = 20 reads worse than the rate a long job sees. Never `value`.
+    steady = None
+    if args.steps < 100 and not args.no_steady:
+        ks = 200
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(ks):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dts, tot_s, _ = sharding.aggregate(time.perf_counter() - t1, units, device)
+        steady = {"steps": ks, "value": round(tot_s * ks / dts, 1), "ms_per_step": round(dts / ks * 1e3, 4),
+                  "note": "the same step, %d more of them timed after the contract's %d (not part of `value`)" % (ks, args.steps)}
+
     # parity spot check against the CPU oracle on the first streams of this rank's batch (not timed)
     max_err, cpu = None, None
     if b is not None and rank == 0:
@@ -572,6 +590,7 @@ def main():
                          "algorithmic_bytes_per_packet": round(bytes_per_unit, 1)},
             "cpu_baseline": cpu, "pcm_stage_s16": pcm_stage,
             "pcm_max_abs_err_vs_oracle": max_err, "pcm_peak": None if max_err is None else pcm_peak,
+            "steady_state": steady,
         }
         print(json.dumps(line))
     if world > 1:

@@ -11,11 +11,19 @@ import sys
 
 csv.field_size_limit(1 << 30)
 root = sys.argv[1]
+
+
+def kname(raw):
+    """'void vsyn_residue_vq_kernel<true>(...)' -> 'vsyn_residue_vq_kernel<true>'; plain kernels unchanged"""
+    n = raw.split("(")[0].strip()
+    return n[5:] if n.startswith("void ") else n
+
+
 out = {"kernels": {}}
 for path in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
-        if row["Name"].startswith("vsyn_"):
-            k = out["kernels"].setdefault(row["Name"].split("(")[0], {})
+        if kname(row["Name"]).startswith("vsyn_"):
+            k = out["kernels"].setdefault(kname(row["Name"]), {})
             k["calls"] = int(row["Calls"])
             k["avg_ns"] = float(row["AverageNs"])
             k["min_ns"] = float(row["MinNs"])
@@ -23,7 +31,7 @@ for path in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), re
 for path in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     per = collections.defaultdict(lambda: collections.defaultdict(float))  # (kernel, counter) -> dispatch -> value
     for row in csv.DictReader(open(path)):
-        name = row["Kernel_Name"].split("(")[0]
+        name = kname(row["Kernel_Name"])
         if name.startswith("vsyn_"):
             per[(name, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
     for (name, ctr), d in per.items():
