@@ -352,9 +352,9 @@ OkOrError VorbisResidue::parse(BitReader& reader, int num_codebooks) {
   for (int i = 0; i < num_classifications; ++i)
     for (int j = 0; j < 8; ++j)
       if (cascades[(size_t)i] & (1u << j)) {
-        const uint32_t b = reader.readBitsT<8>();
-        CHECK((int)b < num_codebooks);
-        books[(size_t)i * 8 + j] = (int16_t)b;
+        // (not checked against the codebook count here: the reference reads it unchecked, hpp:656, and only a packet that USES
+        // such an entry fails; decode / decode_entries check at that point)
+        books[(size_t)i * 8 + j] = (int16_t)reader.readBitsT<8>();
       }
   return OkOrError();
 }
@@ -399,6 +399,7 @@ OkOrError VorbisResidue::decode(BitReader& reader, const std::vector<VorbisCodeb
           if (!channel_used[j]) continue;
           const int book = books[(size_t)cls[(size_t)j * per_ch + pc] * 8 + (size_t)pass];
           if (book < 0) continue;
+          CHECK((size_t)book < codebooks.size());  // (the reference indexes out of range here, hpp:731)
           const VorbisCodebook& vq = codebooks[(size_t)book];
           float* v = out[j];
           const uint32_t offset = lim_begin + pc * partition_size;
@@ -434,7 +435,9 @@ void VorbisResidue::prepare(const std::vector<VorbisCodebook>& codebooks) {
   runs.assign((size_t)num_classifications * 8, Run());
   for (size_t k = 0; k < runs.size() && k < books.size(); ++k) {
     const int b = books[k];
-    if (b < 0 || (size_t)b >= codebooks.size()) continue;
+    if (b < 0) continue;
+    runs[k].count = 0xFFFFFFFFu;  // a book that cannot be decoded from: an error for the packet that uses it
+    if ((size_t)b >= codebooks.size()) continue;
     const VorbisCodebook& vq = codebooks[(size_t)b];
     if (!vq.dimensions_ || vq.fast_.empty()) continue;
     runs[k].fast = vq.fast_.data();
@@ -558,7 +561,10 @@ OkOrError VorbisResidue::decode_entries(BitReader& reader, const std::vector<Vor
         for (uint32_t j = 0; j < num_channel; ++j) {
           if (!channel_used[j]) continue;
           const Run& R = runs[(size_t)cls[(size_t)j * per_ch + pc] * 8 + (size_t)pass];
-          if (!R.fast) continue;
+          if (!R.fast) {
+            CHECK(R.count == 0u);  // (0xffffffff: the class names a codebook that does not exist / has no code words)
+            continue;
+          }
           CHECK(R.book->lookup_type_ != 0);  // decodeVector on a scalar-only book
           room(R.count);
           uint16_t* dst = entries_out.data() + at;
