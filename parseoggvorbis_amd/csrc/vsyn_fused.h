@@ -635,6 +635,8 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
         float* dn = out + shift + MS - 2u - 2u * kap;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          // (plain stores: a packet gets 64 contiguous bytes per instruction here, half a cache line — as streaming stores those
+          // partial lines cost config 4 9 %; the long blocks' 512-byte rows are what the non-temporal hint is for)
           *(float2*)(up + 16 * j) = f2(oh_s[j], n_s[j]);
           *(float2*)(dn - 16 * j) = f2(n_m[j], oh_m[j]);
         }
@@ -765,7 +767,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   if (!MIXED) {
     const float2* src = (const float2*)(A.residue + pi.res_off + (size_t)c * ML) + lane0;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
+    for (int t = 0; t < 8; ++t) raw[t] = stream_load2(src + 64 * t);
   }
   if (MIXED && qa == 0 && si.has_carry && !pi.bad) {
     // the previous submit left this stream's windowed right half in natural order (carry_n / 2 samples)
@@ -928,7 +930,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     if (!MIXED) {
       const float2* src = (const float2*)(A.residue + pin.res_off + (size_t)c * ML) + lane;  // one 64-bit add, immediate offsets
 #pragma unroll
-      for (int t = 0; t < 8; ++t) raw[t] = src[64 * t];
+      for (int t = 0; t < 8; ++t) raw[t] = stream_load2(src + 64 * t);
     } else {
 #ifdef VSYN_MIXED_PREFETCH
       // Measured (config 4): the 16 registers this keeps live across the floor product, FFT and overlap do not exist in the 128-VGPR
@@ -1203,8 +1205,13 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         float* dn = out + 1022u - 2u * kappa;    // samples 1022-s, 1023-s
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          *(float2*)(up + 128 * j) = f2(oh_s[j], n_s[j]);
-          *(float2*)(dn - 128 * j) = f2(n_m[j], oh_m[j]);
+          if (!MIXED) {  // steady runs: whole 512-byte rows, written once, never read back -> streamed (non-temporal)
+            stream_store2(up + 128 * j, oh_s[j], n_s[j]);
+            stream_store2(dn - 128 * j, n_m[j], oh_m[j]);
+          } else {  // (mixed runs: chunks of different store shapes share cache lines; streaming them cost config 4 9 %)
+            *(float2*)(up + 128 * j) = f2(oh_s[j], n_s[j]);
+            *(float2*)(dn - 128 * j) = f2(n_m[j], oh_m[j]);
+          }
         }
       } else if (emit) {
         if (MIXED) dma_younger = 0xFFu;

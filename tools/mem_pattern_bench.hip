@@ -16,7 +16,7 @@
 
 constexpr uint32_t BLK = 1024;  // floats per block (one channel of one long packet)
 
-template <int WIDTH, bool LINEAR, bool WRITE>
+template <int WIDTH, bool LINEAR, bool WRITE, int NT = 0>
 __global__ void __launch_bounds__(512, 4) walk(const float* __restrict__ in, float* __restrict__ out, uint32_t streams, uint32_t runs, uint32_t R,
                                                 uint32_t ppk, uint64_t plane, int pace) {
   const uint32_t wave = blockIdx.x * 8 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -38,12 +38,12 @@ __global__ void __launch_bounds__(512, 4) walk(const float* __restrict__ in, flo
   {
     const vec* p = src_of(0);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) cur[i] = p[64 * i];
+    for (int i = 0; i < NI; ++i) cur[i] = (NT & 1) ? __builtin_nontemporal_load(p + 64 * i) : p[64 * i];
   }
   for (uint32_t q = 0; q < R; ++q) {
     const vec* p = src_of(q + 1 < R ? q + 1 : q);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) nxt[i] = p[64 * i];
+    for (int i = 0; i < NI; ++i) nxt[i] = (NT & 1) ? __builtin_nontemporal_load(p + 64 * i) : p[64 * i];
     float acc = cur[0][0];
     for (int k = 0; k < pace; ++k) acc = __builtin_fmaf(acc, 1.0001f, 0.5f);
     if (WRITE) {
@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(512, 4) walk(const float* __restrict__ in, flo
       for (int i = 0; i < NI; ++i) {
         vec v = cur[i];
         v[0] += acc * 1e-30f;
-        d[64 * i] = v;
+        if (NT & 2) __builtin_nontemporal_store(v, d + 64 * i);
+        else d[64 * i] = v;
       }
     } else if (acc == 1234.5f) {
       out[wave] = acc;
@@ -166,7 +167,7 @@ static void run_pair(const char* name, const float* in, float* out, uint32_t str
   printf("%-44s: %.3f ms  %.2f TB/s (read + write)\n", name, best, bytes / best / 1e9);
 }
 
-template <int WIDTH, bool LINEAR, bool WRITE>
+template <int WIDTH, bool LINEAR, bool WRITE, int NT = 0>
 static void run(const char* name, const float* in, float* out, uint32_t streams, uint32_t runs, uint32_t R, uint64_t plane, int pace) {
   const uint32_t ppk = runs * R, nwaves = streams * runs * 2;
   hipEvent_t e0, e1;
@@ -175,7 +176,7 @@ static void run(const char* name, const float* in, float* out, uint32_t streams,
   float best = 1e30f;
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipEventRecord(e0, 0));
-    walk<WIDTH, LINEAR, WRITE><<<(nwaves + 7) / 8, 512>>>(in, out, streams, runs, R, ppk, plane, pace);
+    walk<WIDTH, LINEAR, WRITE, NT><<<(nwaves + 7) / 8, 512>>>(in, out, streams, runs, R, ppk, plane, pace);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -197,6 +198,11 @@ int main() {
   CHECK(hipMemset(out, 0, n_out * 4));
   for (int pace : {0}) {
     run<8, false, true>("runs,   8 B/lane", in, out, streams, runs, R, plane, pace);
+    run<8, false, true, 1>("runs,   8 B/lane, nt loads", in, out, streams, runs, R, plane, pace);
+    run<8, false, true, 2>("runs,   8 B/lane, nt stores", in, out, streams, runs, R, plane, pace);
+    run<8, false, true, 3>("runs,   8 B/lane, nt both", in, out, streams, runs, R, plane, pace);
+    run<16, false, true, 3>("runs,   16 B/lane, nt both", in, out, streams, runs, R, plane, pace);
+    run<16, true, true, 3>("linear, 16 B/lane, nt both", in, out, streams, runs, R, plane, pace);
     run<16, false, true>("runs,   16 B/lane", in, out, streams, runs, R, plane, pace);
     run<8, true, true>("linear, 8 B/lane", in, out, streams, runs, R, plane, pace);
     run<16, true, true>("linear, 16 B/lane", in, out, streams, runs, R, plane, pace);
