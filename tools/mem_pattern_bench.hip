@@ -63,6 +63,76 @@ __global__ void __launch_bounds__(512, 4) walk(const float* __restrict__ in, flo
   }
 }
 
+
+template <int POL>
+__device__ __forceinline__ float2 pol_load(const float2* p) {
+  float2 v;
+  if (POL == 1) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  else if (POL == 2) asm volatile("global_load_dwordx2 %0, %1, off nt sc1" : "=v"(v) : "v"(p) : "memory");
+  else if (POL == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+  else if (POL == 4) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  else if (POL == 5) asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int POL>
+__device__ __forceinline__ void pol_store(float2* p, float2 v) {
+  if (POL == 1) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  else if (POL == 2) asm volatile("global_store_dwordx2 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
+  else if (POL == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+  else if (POL == 4) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (POL == 5) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+// the kernel's geometry, 8 bytes per lane, cache policy of loads (LP) and stores (SP) spelled out
+template <int LP, int SP>
+__global__ void __launch_bounds__(512, 4) walk_pol(const float* __restrict__ in, float* __restrict__ out, uint32_t streams, uint32_t runs, uint32_t R,
+                                                    uint32_t ppk, uint64_t plane) {
+  const uint32_t wave = blockIdx.x * 8 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t nwaves = streams * runs * 2;
+  if (wave >= nwaves) return;
+  const uint32_t c = wave & 1u, r = (wave >> 1) % runs, s = (wave >> 1) / runs;
+  auto src_of = [&](uint32_t q) { return (const float2*)(in + (((size_t)s * ppk + (size_t)r * R + q) * 2 + c) * BLK) + lane; };
+  auto dst_of = [&](uint32_t q) { return (float2*)(out + ((size_t)s * 2 + c) * plane + ((size_t)r * R + q) * BLK) + lane; };
+  float2 cur[8], nxt[8];
+  {
+    const float2* p = src_of(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = pol_load<LP>(p + 64 * i);
+  }
+  for (uint32_t q = 0; q < R; ++q) {
+    const float2* p = src_of(q + 1 < R ? q + 1 : q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) nxt[i] = pol_load<LP>(p + 64 * i);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    float2* d = dst_of(q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pol_store<SP>(d + 64 * i, cur[i]);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+  }
+}
+template <int LP, int SP>
+static void run_pol(const char* name, const float* in, float* out, uint32_t streams, uint32_t runs, uint32_t R, uint64_t plane) {
+  const uint32_t ppk = runs * R, nwaves = streams * runs * 2;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CHECK(hipEventRecord(e0, 0));
+    walk_pol<LP, SP><<<(nwaves + 7) / 8, 512>>>(in, out, streams, runs, R, ppk, plane);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep && ms < best) best = ms;
+  }
+  const double bytes = (double)nwaves * R * BLK * 4 * 2;
+  printf("%-44s: %.3f ms  %.2f TB/s (read + write)\n", name, best, bytes / best / 1e9);
+}
+
 // one wave per (stream, run), both channels, PK packets (PK x 8 KiB contiguous) per step, one step ahead; 8-byte accesses
 template <int PK>
 __global__ void __launch_bounds__(512) walk_wide(const float* __restrict__ in, float* __restrict__ out, uint32_t streams, uint32_t runs, uint32_t R,
@@ -196,6 +266,19 @@ int main() {
   CHECK(hipMalloc((void**)&out, n_out * 4));
   CHECK(hipMemset(in, 0, n_in * 4));
   CHECK(hipMemset(out, 0, n_out * 4));
+  // cache policies spelled out (loads / stores): 0 default, 1 nt, 2 nt sc1, 3 sc0 sc1 nt, 4 sc1, 5 sc0
+  run_pol<0, 0>("policy: default / default", in, out, streams, runs, R, plane);
+  run_pol<1, 1>("policy: nt / nt", in, out, streams, runs, R, plane);
+  run_pol<2, 2>("policy: nt sc1 / nt sc1", in, out, streams, runs, R, plane);
+  run_pol<3, 3>("policy: sc0 sc1 nt / sc0 sc1 nt", in, out, streams, runs, R, plane);
+  run_pol<1, 2>("policy: nt / nt sc1", in, out, streams, runs, R, plane);
+  run_pol<1, 3>("policy: nt / sc0 sc1 nt", in, out, streams, runs, R, plane);
+  run_pol<2, 1>("policy: nt sc1 / nt", in, out, streams, runs, R, plane);
+  run_pol<3, 1>("policy: sc0 sc1 nt / nt", in, out, streams, runs, R, plane);
+  run_pol<4, 4>("policy: sc1 / sc1", in, out, streams, runs, R, plane);
+  run_pol<5, 5>("policy: sc0 / sc0", in, out, streams, runs, R, plane);
+  run_pol<0, 1>("policy: default / nt", in, out, streams, runs, R, plane);
+  run_pol<1, 0>("policy: nt / default", in, out, streams, runs, R, plane);
   for (int pace : {0}) {
     run<8, false, true>("runs,   8 B/lane", in, out, streams, runs, R, plane, pace);
     run<8, false, true, 1>("runs,   8 B/lane, nt loads", in, out, streams, runs, R, plane, pace);
