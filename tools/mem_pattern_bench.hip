@@ -279,6 +279,12 @@ int main() {
   run_pol<5, 5>("policy: sc0 / sc0", in, out, streams, runs, R, plane);
   run_pol<0, 1>("policy: default / nt", in, out, streams, runs, R, plane);
   run_pol<1, 0>("policy: nt / default", in, out, streams, runs, R, plane);
+  // other run lengths (same bytes): more, shorter runs = the resident waves cover a smaller address window at any time
+  run<8, false, true, 3>("runs of 16 (x2 waves), nt both", in, out, streams, 2 * runs, R / 2, plane, 0);
+  run<8, false, true, 3>("runs of 8 (x4 waves), nt both", in, out, streams, 4 * runs, R / 4, plane, 0);
+  run<8, false, true, 3>("runs of 4 (x8 waves), nt both", in, out, streams, 8 * runs, R / 8, plane, 0);
+  run<8, false, true, 3>("runs of 2 (x16 waves), nt both", in, out, streams, 16 * runs, R / 16, plane, 0);
+  run<8, false, true, 3>("runs of 1 (x32 waves), nt both", in, out, streams, 32 * runs, R / 32, plane, 0);
   for (int pace : {0}) {
     run<8, false, true>("runs,   8 B/lane", in, out, streams, runs, R, plane, pace);
     run<8, false, true, 1>("runs,   8 B/lane, nt loads", in, out, streams, runs, R, plane, pace);
