@@ -22,12 +22,15 @@ def _submit(gpu, b, res, pcm, emit, stream, segs=None, S=None):
                       b["ys"].data_ptr(), res.data_ptr(), pcm.data_ptr(), b["plane"], emit.data_ptr(), None, 0, stream)
 
 
-@pytest.mark.parametrize("workload,ppk", [("long", 1024), ("mixed", 512)])
-def test_full_size_properties(workload, ppk):
+@pytest.mark.parametrize("workload,ppk,bs", [("long", 1024, (256, 2048)), ("mixed", 512, (256, 2048)),
+                                             ("long", 1024, (128, 1024)), ("mixed", 512, (128, 1024)), ("long", 512, (512, 4096))])
+def test_full_size_properties(workload, ppk, bs):
+    """(256, 2048): the tuned kernel's steady and mixed paths; (128, 1024), the long block of 16-22 kHz material, and (512, 4096):
+    the size-generic kernel (one / two register sets) at the same batch sizes."""
     import torch
     import bench
     from tests.workloads import fixture_like_spec
-    spec = fixture_like_spec(2)
+    spec = fixture_like_spec(2, *bs)
     dev = torch.device("cuda", 0)
     S = 64
     b = bench.build_batch(spec, S, ppk, workload, 1234, dev)
@@ -38,6 +41,7 @@ def test_full_size_properties(workload, ppk):
     ysv = b["ys"].view(S, ppk, 2, -1)
     ysv[32:] = ysv[:32]
     gpu = binding.Synth(spec, max_streams=S)
+    assert gpu.fused_paths & 2, gpu.fused_paths  # every one of these setups stays on a fused kernel
     stream = torch.cuda.current_stream().cuda_stream
     pcm1 = torch.zeros((S, 2, b["plane"]), device=dev)
     pcm2 = torch.zeros_like(pcm1)
