@@ -19,20 +19,26 @@
 //               VQ_GROUP consecutive elements of a partition adds their up-to-8 contributions in pass order in registers —
 //               the same sequence of f32 additions as the reference —, then stores each element once (format 2 de-interleaved,
 //               16-byte stores).  No atomics.  Only passes in which the residue has a codebook at all are visited (a scalar loop
-//               over the set bits); vector lengths 1, 2, 4 and 8+ (powers of two) read their entries from LDS and their value
-//               vectors with whole-vector loads through a buffer descriptor over the pool (32-bit offsets, hardware bounds check: an
-//               out-of-range entry number raises the status and can only read other table data or zeros, never outside the pool); format 0, odd lengths and partition tails go through one out-of-line per-element routine.
+//               over the set bits); every power-of-two vector length >= 2 goes through one route (four 8-byte reads per group:
+//               a pair of consecutive elements never straddles a vector), length 1 through eight 4-byte reads; which routes a
+//               residue can need at all is a setup fact (VqResidue::kinds). Format 0, other lengths and partition tails go
+//               through one out-of-line per-element routine.
+//   tables      from the pool in global memory through a buffer descriptor (32-bit offsets, hardware bounds check: an out-of-range
+//               entry number raises the status and can only read other table data or zeros, never outside the pool) — or, for a
+//               setup whose tables fit VQ_IMG_MAX_BYTES, from one copy per workgroup in LDS (vsyn_residue_vq_kernel<true>:
+//               workgroups of several waves, one barrier after staging the copy, then every wave on its own as above).
 //   zero fill   the bins outside the partitions are two runs of consecutive bins per channel.
 // A single wave needs no barriers: its LDS operations execute in order.
-// Measured (bench.py --workload config3_vq, 65 536 stereo long packets, kernel time): this design 0.285 ms (0.294 with plain
-// global loads + a select per entry) — VALU issue is
-// what binds it now (1376 VALU wave-instructions per packet at 45 % lane utilisation: the lanes of a wave hold different
-// classes, so every vector-length variant of a pass runs).  Its predecessor (entries and classifications read from global
-// memory inside the accumulate loop, per-pass LDS book records, zero fill element by element) 0.48 ms; earlier alternatives:
-// workgroup of 128/256 threads per packet 0.67-0.88 ms; separate scan + accumulate kernels (thread = element group, no
-// per-packet loop) 0.69 ms; thread = one entry of a pass with f32 accumulators in LDS 0.69-0.77 ms; forcing 8 waves/SIMD
-// (64 VGPRs, spills) 0.53 ms.  Upper bound of sorting a packet's partitions by class before the accumulate phase (input
-// generated with the classes already sorted, i.e. without the cost of the sort): 0.26 ms — not pursued.
+// Measured (bench.py --workload config3_vq, 65 536 stereo long packets, kernel time; DESIGN.md f-1 has the full record): tables in LDS
+// (synthetic books, 15 KB) 0.225-0.245 ms; the stereo fixture's books (243 KB, global memory) 0.19 ms. Round 1's form of the
+// accumulate phase (one exec-masked variant per vector length, lane-mask error tracking) 0.285 ms; its predecessor (entries and
+// classifications read from global memory inside the accumulate loop, per-pass LDS book records, zero fill element by element)
+// 0.48 ms; earlier alternatives: workgroup of 128/256 threads per packet 0.67-0.88 ms; separate scan + accumulate kernels (thread =
+// element group, no per-packet loop) 0.69 ms; thread = one entry of a pass with f32 accumulators in LDS 0.69-0.77 ms; forcing 8
+// waves/SIMD (64 VGPRs, spills) 0.53 ms. The kernel is bound by its instruction count (~2900 per packet, ~1200 of them on the CU's
+// one scalar unit), not by memory: per-wave time grows linearly with the waves per CU. Measured and dropped in round 2: a two-stage
+// packet pipeline with double-buffered LDS, descriptors one packet ahead by vector load, several groups per lane before any store,
+// lattice books as half vectors in LDS (-DVQ_STAMPS and profiles/r02_experiments/vq_* hold the phase times and A/B runs).
 #pragma once
 #include "vsyn_device.h"
 
