@@ -85,6 +85,33 @@ int main() {
       }
     });
   }
+  {
+    // the same step as a captured graph: pre(i+1) forked from main(i-1), joined before main(i+1); two steps per graph so that the
+    // steady-state dependency pattern is inside it (launch k+1 still serialises behind launch k on stream M)
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    hipEvent_t f0, f1, j0, j1;
+    CHECK(hipEventCreateWithFlags(&f0, hipEventDisableTiming));
+    CHECK(hipEventCreateWithFlags(&f1, hipEventDisableTiming));
+    CHECK(hipEventCreateWithFlags(&j0, hipEventDisableTiming));
+    CHECK(hipEventCreateWithFlags(&j1, hipEventDisableTiming));
+    CHECK(hipStreamBeginCapture(M, hipStreamCaptureModeGlobal));
+    CHECK(hipEventRecord(f0, M));
+    CHECK(hipStreamWaitEvent(P, f0, 0));
+    spin_kernel<<<64, 64, 0, P>>>(SHORT_T, sink);   // pre(a)
+    CHECK(hipEventRecord(j0, P));
+    spin_kernel<<<64, 64, 0, P>>>(SHORT_T, sink);   // pre(b): may overlap main(a)
+    CHECK(hipEventRecord(j1, P));
+    CHECK(hipStreamWaitEvent(M, j0, 0));
+    spin_kernel<<<256, 64, 0, M>>>(LONG_T, sink);   // main(a)
+    CHECK(hipStreamWaitEvent(M, j1, 0));
+    spin_kernel<<<256, 64, 0, M>>>(LONG_T, sink);   // main(b)
+    CHECK(hipStreamEndCapture(M, &g));
+    CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    timeit("captured graph, two steps per launch", [&](int n) {
+      for (int i = 0; i < n; i += 2) CHECK(hipGraphLaunch(ge, M));
+    });
+  }
   timeit("two streams, no ordering between them (lower bound)", [&](int n) {
     for (int i = 0; i < n; ++i) {
       spin_kernel<<<64, 64, 0, P>>>(SHORT_T, sink);
