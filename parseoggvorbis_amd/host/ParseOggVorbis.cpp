@@ -1018,7 +1018,7 @@ OkOrError VorbisStream::parse_audio(const uint8_t* data, uint32_t len, int64_t g
     CHECK_ERR(floor.floor1.decode_ys(reader, setup.codebooks, ys, use));
     used[ch] = use;
     if (use) {
-      own_mask |= 1u << ch;
+      if (ch < 32u) own_mask |= 1u << ch;  // (the synthesis layer takes at most 32 channels; a stream with more never reaches it)
       uint16_t* row = &ys_[row0 + (size_t)ch * ys_stride_];
       for (size_t i = 0; i < ys.size(); ++i) row[i] = (uint16_t)std::min<uint32_t>(ys[i], 0xffffu);
     }
