@@ -28,9 +28,9 @@
 extern "C" {
 #endif
 
-#define VSYN_ABI_VERSION 4 /* 2: + residue VQ stage (vsyn_attach_vq, vsyn_vq_batch), page-locked host buffers; 3: + vsyn_pcm_abs_sum_host,
+#define VSYN_ABI_VERSION 5 /* 2: + residue VQ stage (vsyn_attach_vq, vsyn_vq_batch), page-locked host buffers; 3: + vsyn_pcm_abs_sum_host,
                               vsyn_pcm_fetch_host, VSYN_SUBMIT_KEEP_PCM (additive; the feature taps no longer force the staged kernels);
-                              4: + vsyn_fused_paths (additive) */
+                              4: + vsyn_fused_paths (additive); 5: + VSYN_SUBMIT_PRE_KERNELS (additive) */
 
 #define VSYN_MAX_CHANNELS 32 /* floor_used is a 32-bit mask (reference: uint8_t audio_channels) */
 #define VSYN_MAX_POSTS 65    /* Vorbis I: 2 + 31 partitions x <=8 dims, capped at 65 by the spec */
@@ -144,6 +144,10 @@ typedef struct vsyn_handle vsyn_handle;
                                          pending on hip_stream). Lets the layout + floor-unwrap kernels of this submit overlap the
                                          synthesis kernel of the previous one; results are identical either way. */
 
+#define VSYN_SUBMIT_PRE_KERNELS 8u    /* diagnostics / A-B: prepare the batch (layout scan, floor-1 step 1) with the two chained kernels every
+                                         submit used before ABI 5 (with VSYN_SUBMIT_INPUTS_READY: on an internal stream, ordered by events).
+                                         Default: one dependency-free preparation kernel in front of the synthesis kernel on the caller's
+                                         stream whenever the fused kernels take the whole batch; results are identical either way. */
 #define VSYN_SUBMIT_KEEP_PCM 4u        /* vsyn_submit_host*: leave the PCM on the device (`pcm` may be NULL, nothing is copied back);
                                          fetch it in the form the consumer wants with vsyn_pcm_fetch_host */
 

@@ -20,6 +20,7 @@ VSYN_SEG_RESET = 1
 VSYN_SUBMIT_STAGED = 1
 VSYN_SUBMIT_INPUTS_READY = 2
 VSYN_SUBMIT_KEEP_PCM = 4
+VSYN_SUBMIT_PRE_KERNELS = 8
 VSYN_PCM_S16, VSYN_PCM_F32 = 1, 2
 
 

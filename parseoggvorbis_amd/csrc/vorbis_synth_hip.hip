@@ -20,6 +20,7 @@
 
 #include "vsyn_device.h"
 #include "vsyn_staged.h"
+#include "vsyn_prep.h"
 #include "vsyn_fused.h"
 #include "vsyn_fused_u.h"
 #include "vsyn_vq.h"
@@ -118,20 +119,32 @@ struct vsyn_handle {
   hipStream_t host_stream = nullptr;   // vsyn_submit_host: copies in, kernels, copies out
   hipStream_t side = nullptr;          // the (usually empty) staged work list runs beside the fused kernel
   hipStream_t pre = nullptr;           // layout + floor unwrap of submit i+1 run beside the fused kernel of submit i
-  hipEvent_t ev_join = nullptr, ev_pre_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr};
-  bool main_done_valid[2] = {false, false};
-  bool pre_done_valid[2] = {false, false};
-  hipStream_t last_pre_stream = nullptr;  // stream the previous submit's layout kernel ran on (valid iff pre_done_valid[its half])
+  hipEvent_t ev_join = nullptr, ev_self = nullptr;
+  // Workspace ring: submit i uses slot i % WS_RING. When its preparation kernels run on the internal stream `pre` (beside the previous
+  // submit's synthesis kernel) the slot's previous user, submit i - WS_RING, must be done: known from an event recorded on the caller's
+  // stream behind every EV_EVERY-th submit whose preparation ran there. WS_RING = 2, EV_EVERY = 1 on purpose: a deeper ring lets the
+  // preparation run further ahead, but then its workgroups land in the MIDDLE of an exact-fit synthesis grid instead of at its start
+  // (measured with 8 / 4: config 3's synthesis kernel 0.258 instead of 0.242 ms).
+  static constexpr uint32_t WS_RING = 2, EV_EVERY = 1, EV_RING = 2, CNT_RING = 4;
+  hipEvent_t ev_pre_done[WS_RING] = {}, ev_ring[EV_RING] = {};
+  uint64_t ev_ring_submit[EV_RING] = {~0ull, ~0ull};  // submit index each ring event was recorded behind
+  bool pre_done_valid[WS_RING] = {};
+  hipStream_t last_pre_stream = nullptr;  // stream the previous submit's preparation ran on (valid iff pre_done_valid[its slot])
+  bool last_prep_on_main = false;      // the previous submit's preparation ran on the caller's stream
+  bool last_ran_layout = true;         // the previous submit ran vsyn_layout_kernel (it keeps the staged list counters one slot ahead)
+  uint64_t long_modes = 0;             // bit m: mode m selects a long block
+  uint64_t nsub = 0;                   // submits so far
+  uint32_t prep_lds_bytes = 0;         // dynamic LDS of vsyn_prep_kernel: one 32-bit column of the longest floor's posts per thread
   uint32_t submit_count = 0;
   // workspace
-  // per-batch workspace, double buffered by submit parity so that consecutive submits can overlap
-  DevBuf<uint32_t> ws_list[2];  // staged work list
-  DevBuf<uint32_t> ws_count;    // its counters: a ring of 4 (the layout kernel of submit i clears the slot of submit i+1)
-  DevBuf<PktInfo> ws_info[2];
-  DevBuf<SegInfo> ws_seg[2];
-  DevBuf<uint32_t> ws_segmap[2];
-  DevBuf<uint16_t> ws_fy[2];
-  DevBuf<uint8_t> ws_runcls[2];
+  // per-batch workspace, a ring indexed by the submit number so that the preparation of later submits can run ahead
+  DevBuf<uint32_t> ws_list[WS_RING];  // staged work list
+  DevBuf<uint32_t> ws_count;    // its counters: a ring of CNT_RING (the layout kernel of submit i clears the slot of submit i+1)
+  DevBuf<PktInfo> ws_info[WS_RING];
+  DevBuf<SegInfo> ws_seg[WS_RING];
+  DevBuf<uint32_t> ws_segmap[WS_RING];
+  DevBuf<uint16_t> ws_fy[WS_RING];
+  DevBuf<uint8_t> ws_runcls[WS_RING];
   DevBuf<LayoutChunk> ws_chunks;   // look-back records of the chunked layout scan (segments beyond LAYOUT_CHUNK_PACKETS)
   DevBuf<float> ws_env, ws_blk;
   // host-submit staging
@@ -238,9 +251,29 @@ static int build_const(const vsyn_setup* su, uint32_t max_streams, vsyn_handle* 
       fc.pk[i].dxi = (uint16_t)(sf.xs[i] - sf.xs[lo]);
       fc.pk[i].adx = (uint16_t)(sf.xs[hi] - sf.xs[lo]);
       fc.pk[i].inv_adx = 1.0f / (float)(sf.xs[hi] - sf.xs[lo]);
+      fc.pk[i].idx = i;
+    }
+    {
+      // posts by depth in the neighbour tree (posts 0 and 1 carry their coded values: depth 0), four of one depth to a group
+      std::vector<uint32_t> depth(sf.num_posts, 0);
+      uint32_t maxd = 0;
+      for (uint32_t i = 2; i < sf.num_posts; ++i) {
+        depth[i] = 1u + std::max(depth[fc.lo[i]], depth[fc.hi[i]]);
+        maxd = std::max(maxd, depth[i]);
+      }
+      uint32_t ng = 0;
+      for (uint32_t d = 1; d <= maxd; ++d) {
+        std::vector<uint32_t> at;
+        for (uint32_t i = 2; i < sf.num_posts; ++i)
+          if (depth[i] == d) at.push_back(i);
+        for (size_t k = 0; k < at.size(); k += 4, ++ng)
+          for (uint32_t e = 0; e < 4; ++e) fc.sched[ng][e] = fc.pk[at[std::min(k + e, at.size() - 1)]];
+      }
+      fc.ngroups = ng;  // <= 63 (one group per post at worst)
     }
   }
   H.ys_stride = (maxp + 3u) & ~3u;
+  h->prep_lds_bytes = maxp > 32 ? H.ys_stride * PREP_THREADS * (uint32_t)sizeof(uint32_t) : 16u;  // (floors of <= 32 posts stay in registers)
 
   std::vector<MapConst> maps(su->num_mappings);
   for (uint32_t m = 0; m < su->num_mappings; ++m) {
@@ -353,8 +386,8 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   const ConstHeader& H = h->H;
   HC(hipMalloc((void**)&h->d_const, h->host_const.size()));
   HC(hipMemcpy(h->d_const, h->host_const.data(), h->host_const.size(), hipMemcpyHostToDevice));
-  HC(hipMalloc((void**)&h->d_state, sizeof(StreamState) * max_streams));
-  HC(hipMemset(h->d_state, 0, sizeof(StreamState) * max_streams));
+  HC(hipMalloc((void**)&h->d_state, sizeof(StreamState) * 2 * max_streams));  // two tagged records per slot (vsyn_device.h)
+  HC(hipMemset(h->d_state, 0, sizeof(StreamState) * 2 * max_streams));
   const size_t carry_floats = 2ull * max_streams * H.channels * (H.bs[1] / 2);
   HC(hipMalloc((void**)&h->d_carry, carry_floats * sizeof(float)));
   HC(hipMemset(h->d_carry, 0, carry_floats * sizeof(float)));
@@ -369,12 +402,15 @@ int vsyn_create(const vsyn_setup* setup, int device, uint32_t max_streams, vsyn_
   // vsyn_sync_status, synchronises its stream); the system-scope fence of a default event costs ~3 us per submit
   const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
   HC(hipEventCreateWithFlags(&h->ev_join, evf));
-  for (int b = 0; b < 2; ++b) {
-    HC(hipEventCreateWithFlags(&h->ev_pre_done[b], evf));
-    HC(hipEventCreateWithFlags(&h->ev_main_done[b], evf));
-  }
-  HC(h->ws_count.ensure(4));
-  HC(hipMemset(h->ws_count.p, 0, sizeof(uint32_t) * 4));
+  HC(hipEventCreateWithFlags(&h->ev_self, evf));
+  for (uint32_t k = 0; k < H.num_modes && k < 64; ++k)
+    if (H.mode_blockflag[k]) h->long_modes |= 1ull << k;
+  for (uint32_t b = 0; b < vsyn_handle::WS_RING; ++b) HC(hipEventCreateWithFlags(&h->ev_pre_done[b], evf));
+  for (uint32_t b = 0; b < vsyn_handle::EV_RING; ++b) HC(hipEventCreateWithFlags(&h->ev_ring[b], evf));
+  // (the attribute is per kernel, not per handle: only ever raised, to the largest any setup can need — 68 posts x 256 threads x 4 B)
+  HC(hipFuncSetAttribute((const void*)vsyn_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * PREP_THREADS * 4));
+  HC(h->ws_count.ensure(vsyn_handle::CNT_RING));
+  HC(hipMemset(h->ws_count.p, 0, sizeof(uint32_t) * vsyn_handle::CNT_RING));
   h->fused_mask = h->tuned_mask = fused_ok_mask(h->H, h->host_const.data());
   if ((e = fused_tables_create(h->H, h->host_const.data(), &h->fused)) != hipSuccess) {
     fail(err, VSYN_ERR_HIP, "fused table upload failed: %s", hipGetErrorString(e));
@@ -429,6 +465,25 @@ void vsyn_destroy(vsyn_handle* h) {
     }
   }
 #endif
+#ifdef PREP_STAMPS
+  {  // diagnostic build: cycles per phase of the in-wave preparation (last launch), averaged over the waves that ran one
+    static unsigned long long host[8192][PREP_NSTAMPS];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prep_stamps), sizeof(host)) == hipSuccess) {
+      double sum[PREP_NSTAMPS] = {0};
+      unsigned long long waves = 0;
+      for (int u = 0; u < 8192; ++u) {
+        if (!host[u][PREP_NSTAMPS - 1]) continue;
+        ++waves;
+        for (int i = 0; i + 1 < PREP_NSTAMPS; ++i) sum[i] += (double)host[u][i];
+      }
+      if (waves) {
+        static const char* nm[PREP_NSTAMPS - 1] = {"header + stream state", "scan in front of the run", "descriptors, scan, PktInfo", "floor-1 step 1", "drain + invalidate", "-", "-"};
+        fprintf(stderr, "prep stamps: %llu waves\n", waves);
+        for (int i = 0; i + 1 < PREP_NSTAMPS; ++i) fprintf(stderr, "  %-28s %8.0f cycles\n", nm[i], sum[i] / waves);
+      }
+    }
+  }
+#endif
 #ifdef VSYN_STAMPS
   {  // diagnostic build: per-phase cycles of the LAST launch's steady runs, averaged over the waves that ran one
     static unsigned long long host[8192][VSYN_NSTAMPS];
@@ -458,10 +513,11 @@ void vsyn_destroy(vsyn_handle* h) {
   if (h->pre) (void)hipStreamDestroy(h->pre);
   if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  for (int b = 0; b < 2; ++b) {
+  if (h->ev_self) (void)hipEventDestroy(h->ev_self);
+  for (uint32_t b = 0; b < vsyn_handle::WS_RING; ++b)
     if (h->ev_pre_done[b]) (void)hipEventDestroy(h->ev_pre_done[b]);
-    if (h->ev_main_done[b]) (void)hipEventDestroy(h->ev_main_done[b]);
-  }
+  for (uint32_t b = 0; b < vsyn_handle::EV_RING; ++b)
+    if (h->ev_ring[b]) (void)hipEventDestroy(h->ev_ring[b]);
   if (h->d_const) (void)hipFree(h->d_const);
   if (h->d_vq) (void)hipFree(h->d_vq);
   h->st_curve.release(); h->st_vqpk.release(); h->st_cls.release(); h->st_ent.release();
@@ -470,7 +526,7 @@ void vsyn_destroy(vsyn_handle* h) {
   if (h->d_status) (void)hipFree(h->d_status);
   h->ws_count.release();
   h->ws_chunks.release();
-  for (int b = 0; b < 2; ++b) {
+  for (uint32_t b = 0; b < vsyn_handle::WS_RING; ++b) {
     h->ws_list[b].release(); h->ws_info[b].release(); h->ws_seg[b].release(); h->ws_segmap[b].release(); h->ws_fy[b].release(); h->ws_runcls[b].release();
   }
   h->ws_env.release(); h->ws_blk.release();
@@ -538,7 +594,7 @@ static hipError_t profile_end(vsyn_handle* h, hipStream_t s) {
 int vsyn_reset_streams(vsyn_handle* h, void* hip_stream, const char** err) {
   if (!h) return fail(err, VSYN_ERR_INVALID, "handle is NULL");
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemsetAsync(h->d_state, 0, sizeof(StreamState) * h->H.max_streams, (hipStream_t)hip_stream));
+  HIPCHK(hipMemsetAsync(h->d_state, 0, sizeof(StreamState) * 2 * h->H.max_streams, (hipStream_t)hip_stream));
   return VSYN_OK;
 }
 
@@ -592,14 +648,16 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
                                   : fused_pick_run_len((fmask & 1u) || !use_u ? h->fused.waves_per_cu : (int)h->utab.waves_per_cu, S, C,
                                                        max_seg_packets, h->num_cus);
 
-  // Workspace of this submit (double buffered). With VSYN_SUBMIT_INPUTS_READY the pre-kernels (layout scan, floor
-  // unwrap: latency-bound, ~50 us) go to an internal stream and overlap the previous submit's synthesis kernel; they
-  // only wait until the submit before that has released this workspace half.
-  const uint32_t wb = h->submit_count & 1u;
-  uint32_t* cnt = h->ws_count.p + (h->submit_count & 3u);
-  uint32_t* cnt_next = h->ws_count.p + ((h->submit_count + 1u) & 3u);
+  // Workspace of this submit: slot i % WS_RING of a ring, so that the preparation of later submits can run ahead of the synthesis
+  // kernels (see vsyn_handle).
+  const uint64_t isub = h->nsub++;
+  const uint32_t wb = (uint32_t)(isub % vsyn_handle::WS_RING), wb_prev = (uint32_t)((isub + vsyn_handle::WS_RING - 1u) % vsyn_handle::WS_RING);
+  uint32_t* cnt = h->ws_count.p + (isub % vsyn_handle::CNT_RING);
+  uint32_t* cnt_next = h->ws_count.p + ((isub + 1u) % vsyn_handle::CNT_RING);
   ++h->submit_count;
-  HIPCHK(h->ws_info[wb].ensure(P));
+  // the submit's number tags the stream-state records and the look-back records of the chunked scan; 0 means "never written"
+  const uint32_t epoch = (h->submit_count & 0x3FFFFFFFu) ? h->submit_count : ++h->submit_count;
+  HIPCHK(h->ws_info[wb].ensure((size_t)P + 8));  // (slack: the generic kernel fetches descriptors eight at a time)
   HIPCHK(h->ws_seg[wb].ensure(S));
   HIPCHK(h->ws_segmap[wb].ensure(P));
   HIPCHK(h->ws_list[wb].ensure(2 * (size_t)P + 64));
@@ -615,56 +673,118 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   uint32_t* segmap = h->ws_segmap[wb].p;
   uint32_t* list = h->ws_list[wb].p;
 
-  const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged;
+  // Preparation of the batch (layout scan, floor-1 step 1).
+  //   WHAT: when every run is taken by a fused kernel and no segment is longer than PREP_MAX_SEG_PACKETS, ONE dependency-free kernel
+  //   (vsyn_prep.h). Otherwise (staged kernels, intermediate-signal taps, the residue VQ stage — its kernel needs the packets' offsets
+  //   first —, very long segments, VSYN_SUBMIT_PRE_KERNELS) the layout kernel and the unwrap kernel.
+  //   WHERE: with VSYN_SUBMIT_INPUTS_READY on the internal stream `pre`, ahead of the caller's stream (ordered by one event wait per
+  //   submit); otherwise in front of the synthesis kernel on the caller's stream.
+  static const bool env_no_prep_kernel = getenv("VSYN_NO_PREP_KERNEL") && atoi(getenv("VSYN_NO_PREP_KERNEL"));
+  static const bool env_prep_overlap = getenv("VSYN_PREP_OVERLAP") && atoi(getenv("VSYN_PREP_OVERLAP"));
+  const bool prep_kernel = !force_staged && (fmask & 2u) && !d_vq && max_seg_packets <= PREP_MAX_SEG_PACKETS && !(flags & VSYN_SUBMIT_PRE_KERNELS) && !env_no_prep_kernel;
+  // (the preparation kernel stays on the caller's stream: beside an exact-fit synthesis grid its workgroups cost the synthesis
+  // kernel more than the kernel takes alone — measured 0.254 vs 0.235 ms on config 3; VSYN_PREP_OVERLAP=1 for the A/B)
+  const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged && (!prep_kernel || env_prep_overlap);
   hipStream_t ps = overlap_pre ? h->pre : s;
-  if (h->main_done_valid[wb]) HIPCHK(hipStreamWaitEvent(ps, h->ev_main_done[wb], 0));
-  // The layout kernels of consecutive submits chain through the stream state (abs position, carry parity) and the list-counter
-  // ring: when this submit's pre-kernels run on another stream than the previous submit's did (flags differ between submits),
-  // that order has to be stated.
-  if (h->pre_done_valid[wb ^ 1u] && h->last_pre_stream != ps) HIPCHK(hipStreamWaitEvent(ps, h->ev_pre_done[wb ^ 1u], 0));
-  {
-    // segments longer than LAYOUT_CHUNK_PACKETS are scanned in chunks (a multiple of R each) chained by a look-back; the usual batch
-    // has one chunk per segment
-    const uint32_t chunk_packets = max_seg_packets <= LAYOUT_CHUNK_PACKETS ? runs_per_seg * R : (LAYOUT_CHUNK_PACKETS + R - 1u) / R * R;
-    const uint32_t chunks_per_seg = (max_seg_packets + chunk_packets - 1u) / chunk_packets;
-    const uint32_t lt = std::min(chunk_packets, max_seg_packets) <= LAYOUT_SHORT_PACKETS ? LAYOUT_THREADS_SHORT : LAYOUT_THREADS;
-    if (chunks_per_seg > 1) {
-      const size_t need = (size_t)S * chunks_per_seg;
-      if (need > h->ws_chunks.cap) {
-        HIPCHK(h->ws_chunks.ensure(need));
-        HIPCHK(hipMemsetAsync(h->ws_chunks.p, 0, h->ws_chunks.cap * sizeof(LayoutChunk), ps));  // flags are epoch-tagged: cleared once
+  if (ps != s) {
+    // the slot's previous user, submit isub - WS_RING, has to be done: the first ring event recorded at or behind it says so
+    if (isub >= vsyn_handle::WS_RING) {
+      const uint64_t need = isub - vsyn_handle::WS_RING;
+      const uint64_t jstar = need + ((vsyn_handle::EV_EVERY - 1u) - need % vsyn_handle::EV_EVERY);  // first j >= need with j % EV_EVERY == EV_EVERY - 1
+      const uint32_t slot = (uint32_t)((jstar / vsyn_handle::EV_EVERY) % vsyn_handle::EV_RING);
+      if (h->ev_ring_submit[slot] == jstar) {
+        HIPCHK(hipStreamWaitEvent(ps, h->ev_ring[slot], 0));
+      } else {  // that submit's preparation ran on the caller's stream (no record): order behind everything queued there so far
+        HIPCHK(hipEventRecord(h->ev_self, s));
+        HIPCHK(hipStreamWaitEvent(ps, h->ev_self, 0));
       }
     }
-    if ((uint64_t)S * chunks_per_seg > 0x7FFFFFFFull) return fail(err, VSYN_ERR_INVALID, "too many layout chunks");
-    vsyn_layout_kernel<<<S * chunks_per_seg, lt, layout_lds_bytes(lt, chunk_packets), ps>>>(
-        h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len, h->d_status, R, force_staged ? 0u : fmask, list, cnt,
-        cnt_next, segmap, h->ws_runcls[wb].p, runs_per_seg, chunk_packets, chunks_per_seg, h->ws_chunks.p, h->submit_count);
+    if (h->last_prep_on_main && isub > 0) {
+      // the previous submit left the stream state from a kernel on the caller's stream
+      HIPCHK(hipEventRecord(h->ev_self, s));
+      HIPCHK(hipStreamWaitEvent(ps, h->ev_self, 0));
+    }
   }
-  // Floor unwrap: a kernel of its own. The consuming waves can do it themselves (wave_unwrap in vsyn_fused.h, VSYN_UNWRAP_IN_WAVE=1,
-  // only when every run of the batch is taken by a fused kernel) — measured on config 3: the 4096 waves then all spend their first
-  // ~12 us in the serial post chain with the memory pipe idle (kernel 0.251 -> 0.263 ms, step 0.270 -> 0.281 ms), which costs more
-  // than the separate kernel's interference with the exact-fit grid; kept for batches too small to fill the chip.
+  // Consecutive preparations chain through the stream state (abs position, carry parity) and the list-counter ring: when this one
+  // runs on another stream than the previous one did (flags differ between submits), that order has to be stated.
+  if (h->pre_done_valid[wb_prev] && h->last_pre_stream != ps) HIPCHK(hipStreamWaitEvent(ps, h->ev_pre_done[wb_prev], 0));
   const bool staged_may_work_pre = force_staged || !(fmask & 2u);
-  const bool unwrap_in_wave = !staged_may_work_pre && getenv("VSYN_UNWRAP_IN_WAVE") && atoi(getenv("VSYN_UNWRAP_IN_WAVE"));
-  if (!unwrap_in_wave) {
-    const uint32_t rows = P * C;
-    vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,
-                                                                                                       d_ys, fy, h->d_status);
+  if (!prep_kernel) {
+    // the list-counter ring is cleared one submit ahead by the layout kernel; submits that ran none in between break that chain
+    if (!h->last_ran_layout) HIPCHK(hipMemsetAsync(h->ws_count.p, 0, sizeof(uint32_t) * vsyn_handle::CNT_RING, ps));
+    {
+      // segments longer than LAYOUT_CHUNK_PACKETS are scanned in chunks (a multiple of R each) chained by a look-back; the usual batch
+      // has one chunk per segment
+      const uint32_t chunk_packets = max_seg_packets <= LAYOUT_CHUNK_PACKETS ? runs_per_seg * R : (LAYOUT_CHUNK_PACKETS + R - 1u) / R * R;
+      const uint32_t chunks_per_seg = (max_seg_packets + chunk_packets - 1u) / chunk_packets;
+      const uint32_t lt = std::min(chunk_packets, max_seg_packets) <= LAYOUT_SHORT_PACKETS ? LAYOUT_THREADS_SHORT : LAYOUT_THREADS;
+      if (chunks_per_seg > 1) {
+        const size_t need = (size_t)S * chunks_per_seg;
+        if (need > h->ws_chunks.cap) {
+          HIPCHK(h->ws_chunks.ensure(need));
+          HIPCHK(hipMemsetAsync(h->ws_chunks.p, 0, h->ws_chunks.cap * sizeof(LayoutChunk), ps));  // flags are epoch-tagged: cleared once
+        }
+      }
+      if ((uint64_t)S * chunks_per_seg > 0x7FFFFFFFull) return fail(err, VSYN_ERR_INVALID, "too many layout chunks");
+      vsyn_layout_kernel<<<S * chunks_per_seg, lt, layout_lds_bytes(lt, chunk_packets), ps>>>(
+          h->d_const, P, d_packets, S, d_segments, plane_stride, info, sinfo, h->d_state, d_emit_len, h->d_status, R, force_staged ? 0u : fmask, list, cnt,
+          cnt_next, segmap, h->ws_runcls[wb].p, runs_per_seg, chunk_packets, chunks_per_seg, h->ws_chunks.p, epoch);
+    }
+    {
+      const uint32_t rows = P * C;
+      vsyn_floor_unwrap_kernel<<<(rows + UNWRAP_THREADS - 1) / UNWRAP_THREADS, UNWRAP_THREADS, 0, ps>>>(h->d_const, P, nullptr, nullptr, info,
+                                                                                                         d_ys, fy, h->d_status);
+    }
+    if (d_vq) {
+      if (h->profile_which == 3) HIPCHK(profile_begin(h, ps, "vsyn_residue_vq_kernel"));
+      if (h->vq_tables_in_lds)
+        vsyn_residue_vq_kernel<true><<<std::min<uint32_t>((P + h->vq_waves - 1u) / h->vq_waves, h->vq_grid), VQ_THREADS * h->vq_waves, h->vq_lds_bytes, ps>>>(
+            h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
+      else
+        vsyn_residue_vq_kernel<false><<<std::min<uint32_t>(P, h->vq_grid), VQ_THREADS, h->vq_lds_bytes, ps>>>(
+            h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
+    }
+    if (d_vq && h->profile_which == 3) HIPCHK(profile_end(h, ps));
+  } else {
+    PrepCtx pc;
+    pc.cb = h->d_const;
+    pc.packets = d_packets;
+    pc.segs = d_segments;
+    pc.ys = d_ys;
+    pc.fy = fy;
+    pc.info = info;
+    pc.sinfo = sinfo;
+    pc.state = h->d_state;
+    pc.status = h->d_status;
+    pc.emit_len = d_emit_len;
+    pc.run_cls = h->ws_runcls[wb].p;
+    pc.plane_stride = plane_stride;
+    pc.long_modes = h->long_modes;
+    pc.S = S;
+    pc.R = R;
+    pc.runs_per_seg = runs_per_seg;
+    pc.fused_ok = fmask;
+    pc.P = P;
+    pc.epoch = epoch;
+    // a workgroup takes whole runs, as many as give about PREP_THREADS (packet, channel) rows
+    const uint32_t ppp = std::max<uint32_t>(1u, PREP_THREADS / C);
+    pc.chunk_runs = std::max<uint32_t>(1u, ppp / R);
+    pc.chunks_per_seg = (runs_per_seg + pc.chunk_runs - 1u) / pc.chunk_runs;
+    const uint64_t wgs = (uint64_t)S * pc.chunks_per_seg;
+    if (wgs > 0x7FFFFFF0ull) return fail(err, VSYN_ERR_INVALID, "too many runs");
+    vsyn_prep_kernel<<<(uint32_t)wgs, PREP_THREADS, h->prep_lds_bytes, ps>>>(pc);
   }
-  if (d_vq) {
-    if (h->profile_which == 3) HIPCHK(profile_begin(h, ps, "vsyn_residue_vq_kernel"));
-    if (h->vq_tables_in_lds)
-      vsyn_residue_vq_kernel<true><<<std::min<uint32_t>((P + h->vq_waves - 1u) / h->vq_waves, h->vq_grid), VQ_THREADS * h->vq_waves, h->vq_lds_bytes, ps>>>(
-          h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
-    else
-      vsyn_residue_vq_kernel<false><<<std::min<uint32_t>(P, h->vq_grid), VQ_THREADS, h->vq_lds_bytes, ps>>>(
-          h->d_const, h->d_vq, P, info, d_vq->packets, d_vq->cls, d_vq->num_cls, d_vq->entries, d_vq->num_entries, d_residue, h->d_status);
+  h->last_ran_layout = !prep_kernel;
+  h->last_prep_on_main = ps == s;
+  if (ps != s) {
+    HIPCHK(hipEventRecord(h->ev_pre_done[wb], ps));
+    h->pre_done_valid[wb] = true;
+    HIPCHK(hipStreamWaitEvent(s, h->ev_pre_done[wb], 0));
+  } else {
+    h->pre_done_valid[wb] = false;  // (ordered by the caller's stream itself)
   }
-  if (d_vq && h->profile_which == 3) HIPCHK(profile_end(h, ps));
-  HIPCHK(hipEventRecord(h->ev_pre_done[wb], ps));
-  h->pre_done_valid[wb] = true;
   h->last_pre_stream = ps;
-  if (ps != s) HIPCHK(hipStreamWaitEvent(s, h->ev_pre_done[wb], 0));
+  (void)staged_may_work_pre;
 
   // staged kernels walk the work list the layout kernel built: everything when forced, otherwise only the runs the
   // fused kernel declines (short / mixed blocks, carry-in). In fused mode they run on a forked side stream beside the
@@ -674,7 +794,14 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   const bool staged_may_work = force_staged || !(fmask & 2u);
   hipStream_t ss = force_staged ? s : h->side;
   if (staged_may_work) {
-    if (!force_staged) HIPCHK(hipStreamWaitEvent(h->side, h->ev_pre_done[wb], 0));
+    if (!force_staged) {  // the side stream starts behind the preparation
+      if (ps != s) {
+        HIPCHK(hipStreamWaitEvent(h->side, h->ev_pre_done[wb], 0));
+      } else {
+        HIPCHK(hipEventRecord(h->ev_self, s));
+        HIPCHK(hipStreamWaitEvent(h->side, h->ev_self, 0));
+      }
+    }
     // residue floats upper bound (the descriptors are device resident, so the exact sum is not known here)
     const size_t bound = (size_t)P * C * (H.bs[1] / 2);
     float* env = taps && taps->after_envelope ? taps->after_envelope : nullptr;
@@ -709,7 +836,6 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     a.residue = d_residue;
     a.curve = taps ? taps->floor_curve : nullptr;
     a.fy = fy;
-    a.ys = unwrap_in_wave ? d_ys : nullptr;
     a.pcm = d_pcm;
     a.carry = h->d_carry;
     a.status = h->d_status;
@@ -739,8 +865,11 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     }
     if (staged_may_work) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   }
-  HIPCHK(hipEventRecord(h->ev_main_done[wb], s));
-  h->main_done_valid[wb] = true;
+  if (ps != s && isub % vsyn_handle::EV_EVERY == vsyn_handle::EV_EVERY - 1u) {  // (a record costs ~4.6 us between two synthesis kernels)
+    const uint32_t slot = (uint32_t)((isub / vsyn_handle::EV_EVERY) % vsyn_handle::EV_RING);
+    HIPCHK(hipEventRecord(h->ev_ring[slot], s));
+    h->ev_ring_submit[slot] = isub;
+  }
   h->last_S = S;
   h->last_wb = wb;
   HIPCHK(hipGetLastError());
@@ -800,7 +929,17 @@ int vsyn_attach_vq(vsyn_handle* h, const vsyn_vq_setup* vq, const char** err) {
       if (const char* e = getenv("VSYN_VQ_WAVES_PER_WG")) best_w = (uint32_t)std::max(1, std::min(16, atoi(e)));
       if (best_w) {
         const uint32_t lds = tab_bytes + best_w * wave_bytes;
-        HIPCHK(hipFuncSetAttribute((const void*)vsyn_residue_vq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+          // the attribute belongs to the kernel, not to the handle: only ever raise it, or a handle with smaller tables would pull the
+          // limit below what an older handle still launches with
+          static std::mutex mu_attr;
+          static uint32_t cur_max = 0;
+          std::lock_guard<std::mutex> lk2(mu_attr);
+          if (lds > cur_max) {
+            HIPCHK(hipFuncSetAttribute((const void*)vsyn_residue_vq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            cur_max = lds;
+          }
+        }
         int per_cu = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vsyn_residue_vq_kernel<true>, (int)(VQ_THREADS * best_w), lds));
         if (per_cu > 0) {

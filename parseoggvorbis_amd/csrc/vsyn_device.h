@@ -9,13 +9,14 @@
 //                   pcm f32 [S][C][plane_stride]  — caller owned.
 //   workspace       PktInfo [P] (32 B), SegInfo [S], unwrapped floor posts u16 [P][C][ys_stride];
 //                   staged path only: after_envelope f32 (residue-shaped) and pcm_after_mdct f32 (2x).
-//   stream state    StreamState [max_streams] + overlap carry f32 [2][max_streams][C][blocksize1/2]
+//   stream state    StreamState [max_streams][2] (tagged records, see below) + overlap carry f32 [2][max_streams][C][blocksize1/2]
 //                   (double buffered: a submit reads one half and writes the other).
 #pragma once
 #include <stdint.h>
 
 #include "../../include/vorbis_synth_hip.h"
 
+#define VSYN_SCHED_GROUPS 64
 #define VSYN_MAX_TABLES 64 /* Vorbis I: floor/mapping/mode counts are 6-bit fields (hpp:923,941,950) */
 
 struct FloorConst {               // one floor-1 configuration (VorbisFloor1, hpp:416-471) + precomputed neighbours
@@ -29,8 +30,13 @@ struct FloorConst {               // one floor-1 configuration (VorbisFloor1, hp
     uint16_t lo, hi;                       // neighbour header indices
     uint16_t dxi, adx;                     // xs[i] - xs[lo], xs[hi] - xs[lo]
     float inv_adx;                         // 1 / adx
-    uint32_t pad;
+    uint32_t idx;                          // (sched[] only) header index of the post
   } pk[VSYN_MAX_POSTS + 1];
+  // Step 1 as a schedule of GROUPS of up to four mutually independent posts (same depth in the neighbour tree: a post depends on
+  // its two neighbours only): a lane that unwraps a row works on four posts at once instead of one (vsyn_prep.h). Unused entries of
+  // a group repeat its last post. At most posts - 2 <= 63 groups.
+  uint32_t ngroups, pad_[3];
+  PostK sched[VSYN_SCHED_GROUPS][4];
 };
 
 struct MapConst {                 // VorbisMapping (hpp:765-814), synthesis-relevant part
@@ -68,8 +74,13 @@ struct SegInfo {
 
 struct StreamState {              // VorbisStreamDecodeState (hpp:975-1115) reduced to what crosses a batch boundary
   uint64_t abs_total_pos;
-  uint32_t has_prev, prev_n, parity, pad;
+  uint32_t has_prev, prev_n, parity;
+  uint32_t tag;                   // submit number that wrote the record (0: never written)
 };
+// Two records per stream slot. A submit READS the newer record written by an earlier submit and WRITES the other one, tagged with its
+// own number: every wave of a submit — whenever it starts, the segment's last wave may long have finished — finds the state the
+// stream had BEFORE this submit (a record tagged with the reader's own submit number is not a candidate, and the record being
+// overwritten is by construction the older one: even a torn read of it loses the comparison). Submit numbers start at 1 and skip 0.
 
 struct DevStatus {
   uint32_t flags, first_bad_packet;
@@ -110,5 +121,23 @@ __device__ __forceinline__ const float* win_of(const uint8_t* cb, int b, int wid
 __device__ __forceinline__ void raise_status(DevStatus* st, uint32_t flag, uint32_t pkt) {
   atomicOr(&st->flags, flag);
   atomicMin(&st->first_bad_packet, pkt);
+}
+
+// the state a stream slot had before submit `epoch`; *slot = the record it was read from (state_write takes the other one)
+__device__ __forceinline__ StreamState state_read(const StreamState* __restrict__ st, uint32_t stream, uint32_t epoch, uint32_t* slot) {
+  const StreamState a = st[2u * stream], b = st[2u * stream + 1u];
+  const uint32_t da = (a.tag == 0u || a.tag == epoch) ? 0xFFFFFFFFu : epoch - a.tag;
+  const uint32_t db = (b.tag == 0u || b.tag == epoch) ? 0xFFFFFFFFu : epoch - b.tag;
+  if (da <= db) {
+    *slot = 0u;
+    if (da == 0xFFFFFFFFu) return StreamState{0, 0, 0, 0, 0};
+    return a;
+  }
+  *slot = 1u;
+  return b;
+}
+__device__ __forceinline__ void state_write(StreamState* __restrict__ st, uint32_t stream, uint32_t read_slot, StreamState ns, uint32_t epoch) {
+  ns.tag = epoch;
+  st[2u * stream + (read_slot ^ 1u)] = ns;
 }
 #endif

@@ -91,9 +91,7 @@ struct FusedArgs {
   uint16_t* curve;         // feature tap "floor1 floor" (vsyn_taps.floor_curve) or nullptr; written by the tap variant of the kernel only
   const uint8_t* run_cls;  // [S][runs_per_seg] from the layout kernel: 1 steady long run, 2 mixed-block run, 0 staged, 0xFF none
   const float* residue;
-  const uint16_t* ys;      // coded floor rows: non-null = every wave unwraps the rows of its own run itself (wave_unwrap) into `fy` first;
-                           // null = the unwrap kernel has filled `fy`
-  uint16_t* fy;
+  const uint16_t* fy;      // unwrapped floor rows (vsyn_prep_kernel / vsyn_floor_unwrap_kernel)
   float* pcm;
   float* carry;
   DevStatus* status;
@@ -293,115 +291,6 @@ __device__ __forceinline__ PktScalars pkt_load(const PktInfo* p) {  // p wave-un
   return pkt_fields(*(const_words)(uintptr_t)p);
 }
 
-// Floor-1 amplitude unwrap (hpp:521-559) of the rows a wave is about to consume — packets [q0, qb) of its segment, its channel —
-// done by the wave itself: one LANE per row, the posts of all rows in the wave's (still idle) exchange image. Same arithmetic as
-// vsyn_floor_unwrap_kernel (vsyn_staged.h), same output rows in the same buffer, which the packet loop then reads back through L2.
-// Why here: as a kernel of its own the unwrap is 23 us of dependent latency in front of every synthesis launch, or — overlapped
-// with the previous launch — 2048 waves that take wave slots from an exact-fit grid; inside the consumer it is ~25 VALU per packet
-// on a memory-bound kernel. Rows of one floor are processed together (per-post constants through the scalar unit); amplitudes are
-// kept as 16 bits, saturating: anything beyond renders >= 256 and flags the packet either way.
-typedef __attribute__((address_space(3))) uint16_t lds_u16;
-__device__ __forceinline__ void wave_unwrap(const FusedArgs& A, float2* xb_mem, const uint32_t lane, const vsyn_segment sg, const uint32_t q0, const uint32_t qb,
-                                            const uint32_t C, const uint32_t c) {
-  const uint8_t* __restrict__ cb = A.cb;
-  const ConstHeader* H = hdr_of(cb);
-  const uint32_t stride = __builtin_amdgcn_readfirstlane(H->ys_stride);
-  const uint32_t CH = min(64u, (FUSED_XSLOTS * 8u) / (2u * stride));  // rows per chunk: the image holds [stride][CH] 16-bit posts
-  lds_u16* const sfy = (lds_u16*)(lds_u32*)xb_mem;
-  const MapConst* const maps = (const MapConst*)(cb + H->off_map);
-  const FloorConst* const floors = (const FloorConst*)(cb + H->off_floor);
-  const PktInfo* const ip = A.info + sg.first_packet;
-  for (uint32_t qs = q0; qs < qb; qs += CH) {
-    const uint32_t q = qs + lane;
-    const bool row_ok = lane < CH && q < qb;
-    uint32_t own = 0, r7 = 0x100u;
-    if (row_ok) {
-      const uint32_t* w = (const uint32_t*)(ip + q);
-      own = w[5];
-      r7 = w[7];
-    }
-    const bool act0 = row_ok && !((r7 >> 8) & 0xFFu) && ((own >> c) & 1u);
-    uint32_t fl_id = 0xFFFFFFFFu;
-    if (act0) fl_id = maps[r7 & 0xFFu].chfloor[c];
-    const uint32_t p = sg.first_packet + q;
-    const size_t gid = (size_t)p * C + c;
-    uint64_t todo = __ballot(act0);
-    while (todo) {
-      const uint32_t f = __builtin_amdgcn_readlane(fl_id, (uint32_t)__builtin_ctzll(todo));
-      const bool mine = act0 && fl_id == f;
-      todo &= ~__ballot(mine);
-      const FloorConst* fc = floors + f;
-      const uint32_t posts = __builtin_amdgcn_readfirstlane(fc->posts), range = __builtin_amdgcn_readfirstlane(fc->range),
-                     mult = __builtin_amdgcn_readfirstlane(fc->mult);
-      if (mine) {
-        const uint2* in8 = (const uint2*)(A.ys + gid * stride);
-        for (uint32_t j = 0; j * 4 < posts; ++j) {
-          const uint2 w = in8[j];
-          sfy[(4 * j + 0) * CH + lane] = (uint16_t)(w.x & 0xFFFFu);
-          sfy[(4 * j + 1) * CH + lane] = (uint16_t)(w.x >> 16);
-          sfy[(4 * j + 2) * CH + lane] = (uint16_t)(w.y & 0xFFFFu);
-          sfy[(4 * j + 3) * CH + lane] = (uint16_t)(w.y >> 16);
-        }
-        uint64_t flags_lo = 3;
-        uint32_t flag_64 = 0;
-        bool bad = false;
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(4))) u32x4* const_pk;
-        for (uint32_t i = 2; i < posts; ++i) {
-          const u32x4 kq = *(const_pk)(uintptr_t)&fc->pk[i];  // wave-uniform: scalar load
-          const uint32_t lo = kq.x & 0xFFFFu, hi = kq.x >> 16;
-          const uint32_t val = sfy[i * CH + lane];
-          const uint32_t ylo = sfy[lo * CH + lane], yhi = sfy[hi * CH + lane];
-          const uint32_t dxi = kq.y & 0xFFFFu, adx = kq.y >> 16;
-          const bool up = yhi >= ylo;
-          const uint32_t ady = up ? yhi - ylo : ylo - yhi;
-          const uint32_t prod = ady * dxi;
-          uint32_t off = (uint32_t)(((float)prod + 0.5f) * __uint_as_float(kq.z));
-          if (prod >= (1u << 21)) off = prod / adx;
-          const uint32_t predicted = up ? ylo + off : ylo - off;
-          const bool ok = predicted <= range;  // hpp:536
-          const uint32_t pr = ok ? predicted : 0u;
-          const uint32_t high_room = range - pr, low_room = pr;
-          const uint32_t room = min(high_room, low_room) * 2;
-          const uint32_t big = high_room > low_room ? val - low_room + pr : pr - val + high_room - 1;
-          const uint32_t small = (val & 1u) ? pr - (val + 1) / 2 : pr + val / 2;
-          const uint32_t fv = val == 0 ? pr : (val >= room ? big : small);
-          const uint64_t touched = (1ull << lo) | (1ull << hi) | (i < 64 ? 1ull << i : 0ull);
-          if (!bad) {
-            flags_lo |= val != 0 ? touched : 0ull;
-            flag_64 |= (val != 0 && i >= 64) ? 1u : 0u;
-          }
-          sfy[i * CH + lane] = (uint16_t)min(fv, 0xFFFFu);
-          bad = bad || !ok;
-        }
-        uint2* out8 = (uint2*)(A.fy + gid * stride);
-        if (bad) {
-          raise_status(A.status, VSYN_ST_FLOOR_RANGE, p);
-          for (uint32_t j = 0; j * 4 < posts; ++j) {
-            const uint32_t a = 0x8000u | (4 * j + 1 < posts ? 0x80000000u : 0u), b = (4 * j + 2 < posts ? 0x8000u : 0u) | (4 * j + 3 < posts ? 0x80000000u : 0u);
-            out8[j] = make_uint2(a, b);
-          }
-        } else {
-          for (uint32_t j = 0; j * 4 < posts; ++j) {
-            uint32_t w[4];
-#pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-              const uint32_t i = 4 * j + e;
-              const uint32_t fv = i < posts ? (uint32_t)sfy[i * CH + lane] : 0u;
-              uint32_t v = fv * mult;  // hpp:573,578
-              if (v > 0x7FFFu || fv > 0x7FFFu) v = 0x7FFFu;
-              const uint32_t fl = i < 64 ? (uint32_t)((flags_lo >> i) & 1ull) : (i == 64 ? flag_64 : 0u);
-              w[e] = i < posts ? (v | (fl << 15)) : 0u;
-            }
-            out8[j] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
-          }
-        }
-      }
-    }
-  }
-  vmem_drain();  // the rows are read back by this wave: its stores have reached L2
-}
-
 enum { K_REG = 0, K_LDS = 1, K_CARRY = 2 };
 __device__ __forceinline__ uint32_t bitrev6(uint32_t l) { return __brev(l) >> 26; }
 
@@ -443,7 +332,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
 #pragma unroll
   for (uint32_t t = 0; t < 8; ++t) {
     const uint32_t tc = min(t, Jp - 1u);
-    const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], tc) << 32) | __builtin_amdgcn_readlane(da[0], tc);
+    const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], tc) << 32) | (uint32_t)__builtin_amdgcn_readlane(da[0], tc);
     raw[t] = ((const float2*)(A.residue + off + (size_t)c * MS))[lane];
     vrow[t] = (A.fy + ((size_t)(p0 + tc) * C + c) * ys_stride)[sidx];
   }
@@ -528,7 +417,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
       if (t >= Jp) break;
       r[t] = f2(r[t].x * T.invdb[i0[t]], r[t].y * T.invdb[i1[t]]);
       if (TAPC && !((nocurve_mask >> t) & 1u)) {  // feature tap "floor1 floor" (hpp:585): the table indices are the rendered curve
-        const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], t) << 32) | __builtin_amdgcn_readlane(da[0], t);
+        const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], t) << 32) | (uint32_t)__builtin_amdgcn_readlane(da[0], t);
         ((uint32_t*)(A.curve + off + (size_t)c * MS))[lane] = i0[t] | (i1[t] << 16);
       }
     }
@@ -746,9 +635,6 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 
   const uint32_t q0 = qa ? qa - 1 : 0;
   const PktInfo* const ip = A.info + __builtin_amdgcn_readfirstlane(sg.first_packet);
-#ifndef VSYN_NO_WAVE_UNWRAP
-  if (A.ys) wave_unwrap(A, xb, lane0, sg, q0, qb, C, c);
-#endif
   PktScalars pi = pkt_load(ip + q0);
   float2 raw[8];  // own channel's residue, requested one packet ahead (mixed runs: when the next block is a long one, too)
   bool raw_ahead = false;  // MIXED: raw[] already holds (or will hold) this packet's residue

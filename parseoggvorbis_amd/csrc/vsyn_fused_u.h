@@ -259,7 +259,6 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
     vmem_drain();
   };
 
-  if (A.ys) wave_unwrap(A, xb, lane, sg, q0, qb, C, c);
   fetch_info(q0);
   vmem_drain();
   uint32_t it = 0, ep = 0, qnext = q0, steps_done = 0, coupled_passes = 0;  // ep: hand-off rounds so far (the pairwise counters)
@@ -1134,9 +1133,11 @@ static inline hipError_t u_tables_create(const ConstHeader& H, const uint8_t* ho
   ut->waves_per_block = w / grp * grp;
   ut->waves_per_cu = ut->waves_per_block;  // one workgroup per CU (the tables take a quarter of the LDS)
   const void* kfn = ns == 1 ? (const void*)vsyn_fused_u_kernel<1> : (ns == 2 ? (const void*)vsyn_fused_u_kernel<2> : (const void*)vsyn_fused_u_kernel<4>);
-  e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ut->table_bytes + ut->waves_per_block * ut->wave_bytes));
+  // (the attribute belongs to the kernel, not to the handle: one fixed value — the planning budget above — for every handle, so that a
+  // later handle with a smaller LDS block never lowers the limit under an earlier one's launches)
+  e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
   if (e != hipSuccess && getenv("VSYN_DEBUG"))
-    fprintf(stderr, "vsyn: hipFuncSetAttribute(%u B dynamic LDS) failed: %s\n", ut->table_bytes + ut->waves_per_block * ut->wave_bytes, hipGetErrorString(e));
+    fprintf(stderr, "vsyn: hipFuncSetAttribute(%u B dynamic LDS) failed: %s\n", budget, hipGetErrorString(e));
   return e == hipSuccess ? hipSuccess : hipErrorInvalidValue;
 }
 

@@ -68,6 +68,67 @@ __device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_
   return 0;
 }
 
+// One packet of the scan, shared by the layout kernel and the in-wave preparation of the fused kernels (vsyn_prep.h): everything
+// PktInfo holds, from the packet's descriptor, the block size in front of it and the scan's running values (hpp:1019-1067, 1174-1180).
+struct PktStep {
+  PktInfo pi;
+  int64_t abs_after;
+  uint32_t raise;  // VSYN_ST_* to raise for this packet (0: none)
+};
+// (own / used: floor_output_used before and after the nonzero propagate of hpp:1174-1180, see coupling_propagate)
+__device__ __forceinline__ PktStep pkt_step_core(const vsyn_packet& k, bool mode_ok, uint32_t lng, uint32_t mapping, uint32_t n, uint32_t prev_n,
+                                                 int64_t abs_before, int64_t abs0, uint64_t res_off, uint64_t plane_stride, uint32_t own, uint32_t used) {
+  PktStep r;
+  PktInfo pi = {};
+  r.raise = mode_ok ? 0u : (uint32_t)VSYN_ST_BAD_MODE;
+  const uint32_t L = prev_n ? prev_n / 4 + n / 4 : 0;
+  int64_t abs_after = abs_before + L;
+  uint32_t emit = L;
+  bool bad = !mode_ok;
+  if (k.granule >= 0) {
+    // hpp:1029 (position already past the page granule) and hpp:1041 (packets cannot reach it)
+    if (k.granule < abs_before || k.granule > abs_before + (int64_t)L) {
+      r.raise |= VSYN_ST_GRANULE;
+      bad = true;
+      emit = 0;
+    } else {
+      emit = (uint32_t)(k.granule - abs_before);
+    }
+    abs_after = k.granule;
+  }
+  const int64_t rel = abs_before - abs0;
+  if (rel < 0 || (uint64_t)rel + emit > plane_stride) {
+    if (emit) r.raise |= VSYN_ST_PLANE_OVERFLOW;
+    if (emit) bad = true;
+    emit = 0;
+  }
+  pi.res_off = res_off;
+  pi.out_pos = rel < 0 ? 0u : (uint32_t)rel;
+  pi.emit = emit;
+  pi.n = (uint16_t)n;
+  pi.lng = (uint8_t)lng;
+  pi.widx = lng ? (uint8_t)((k.prev_long ? 1 : 0) | (k.next_long ? 2 : 0)) : 0;
+  pi.mapping = (uint8_t)mapping;
+  pi.bad = bad ? 1 : 0;
+  pi.own = own;
+  pi.used = used;
+  r.pi = pi;
+  r.abs_after = abs_after;
+  return r;
+}
+__device__ __forceinline__ PktStep pkt_step(const MapConst* __restrict__ maps, const vsyn_packet& k, bool mode_ok, uint32_t lng, uint32_t mapping,
+                                            uint32_t n, uint32_t prev_n, int64_t abs_before, int64_t abs0, uint64_t res_off,
+                                            uint64_t plane_stride, uint32_t C) {
+  const uint32_t chan_mask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
+  uint32_t own = k.floor_used & chan_mask, used = own;
+  const MapConst* mc = maps + mapping;
+  for (uint32_t i = 0; i < mc->ncoup; ++i) {  // hpp:1175-1180
+    uint32_t m = mc->coup[2 * i], a = mc->coup[2 * i + 1];
+    if (((used >> m) | (used >> a)) & 1u) used |= (1u << m) | (1u << a);
+  }
+  return pkt_step_core(k, mode_ok, lng, mapping, n, prev_n, abs_before, abs0, res_off, plane_stride, own, used);
+}
+
 // A segment is scanned in CHUNKS of chunk_packets packets (a multiple of the run length R, so that a run never straddles two
 // chunks), one workgroup per (segment, chunk). With one chunk per segment — every segment of the batch is at most
 // LAYOUT_CHUNK_PACKETS long: the usual case — nothing below about look-back runs. Longer segments (ONE long stream is the second
@@ -82,7 +143,7 @@ __device__ __forceinline__ uint32_t run_class_bits(const uint32_t* bits, uint32_
 #define LAYOUT_SHORT_PACKETS 256u
 #define LAYOUT_CHUNK_PACKETS 4096u
 struct LayoutChunk {          // look-back record of one (segment, chunk); 48 bytes
-  uint32_t flag;              // epoch * 4 + 1: aggregate valid, + 2: inclusive prefix valid (no clearing between submits)
+  uint32_t flag;              // (epoch & 2^30-1) * 4 + 1: aggregate valid, + 2: inclusive prefix valid, + 3: chain lost (no clearing between submits)
   uint32_t pad;
   int64_t agg_val, inc_val;   // AbsScan of the chunk's own packets / of everything up to its end
   uint64_t agg_res, inc_res;  // residue floats likewise
@@ -131,7 +192,8 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   }
   const uint32_t cn = min(num, cs + chunk_packets) - min(num, cs);  // packets of this chunk
   const bool last_chunk = cs + cn >= num;
-  StreamState st0 = state[sg.stream];
+  uint32_t st_slot;
+  const StreamState st0 = state_read(state, sg.stream, epoch, &st_slot);
   const bool reset = (sg.flags & VSYN_SEG_RESET) != 0;
   const uint32_t carry_n = (!reset && st0.has_prev) ? st0.prev_n : 0;
   const int64_t abs0 = reset ? 0 : (int64_t)st0.abs_total_pos;
@@ -146,6 +208,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   __shared__ uint32_t s_last_n;
   __shared__ AbsScan s_chunk_ex;   // exclusive prefix of this chunk (everything before it in the segment)
   __shared__ uint64_t s_chunk_rex;
+  __shared__ uint32_t s_chunk_lost;
 
   const uint32_t per = (cn + NT - 1) / NT;
   const uint32_t qb = min(cn, t * per), qe = min(cn, qb + per);  // this thread's packets, relative to the chunk
@@ -251,24 +314,31 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
   // chunk chain (segments longer than one chunk only): decoupled look-back over the predecessors' records
   if (chunks_per_seg > 1) {
     if (t == 0) {
+      const uint32_t ep = epoch & 0x3FFFFFFFu;  // the tag shares its word with two state bits
       LayoutChunk* mine = chunks + (size_t)g * chunks_per_seg + ch;
       AbsScan ex = {0, 0};
       uint64_t rex = 0;
+      bool lost = false;  // a predecessor's record never arrived within the bound
       if (ch > 0) {
         mine->agg_val = chunk_agg.val;
         mine->agg_set = (uint32_t)chunk_agg.set;
         mine->agg_res = chunk_res;
-        __hip_atomic_store(&mine->flag, epoch * 4u + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->flag, ep * 4u + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         AbsScan run = {0, 0};  // aggregate of the chunks between the record in hand and this chunk
         uint64_t rrun = 0;
         for (uint32_t pc = ch; pc-- > 0;) {
           LayoutChunk* pr = chunks + (size_t)g * chunks_per_seg + pc;
           uint32_t f;
           uint32_t spins = 0;
-          while (((f = __hip_atomic_load(&pr->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 2) != epoch || (f & 3u) == 0u) {
+          while (((f = __hip_atomic_load(&pr->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 2) != ep || (f & 3u) == 0u) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 24)) break;  // (bounded: a predecessor that never arrives cannot hang the device)
+            if (++spins > (1u << 24)) {  // (bounded: a predecessor that never arrives cannot hang the device; the batch is flagged)
+              lost = true;
+              break;
+            }
           }
+          if ((f & 3u) == 3u) lost = true;  // a predecessor gave up: so does everything behind it, at once
+          if (lost) break;
           if ((f & 3u) == 2u) {
             AbsScan a = {pr->inc_val, (int)pr->inc_set};
             ex = abs_combine(a, run);
@@ -280,19 +350,36 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
           rrun += pr->agg_res;
         }
       }
+      if (lost) raise_status(status, VSYN_ST_BAD_SEGMENT, sg.first_packet);
+      s_chunk_lost = lost ? 1u : 0u;
       const AbsScan incl = abs_combine(ex, chunk_agg);
       mine->inc_val = incl.val;
       mine->inc_set = (uint32_t)incl.set;
       mine->inc_res = rex + chunk_res;
-      __hip_atomic_store(&mine->flag, epoch * 4u + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&mine->flag, ep * 4u + (lost ? 3u : 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       s_chunk_ex = ex;
       s_chunk_rex = rex;
     }
   } else if (t == 0) {
     s_chunk_ex = AbsScan{0, 0};
     s_chunk_rex = 0;
+    s_chunk_lost = 0u;
   }
   __syncthreads();
+  if (s_chunk_lost) {
+    // the chain broke in front of this chunk (flagged above): its positions are unknown — mark its packets bad and its runs absent
+    // instead of laying them out from a record that was never validated
+    for (uint32_t r = ch * runs_per_chunk + t; r < min(runs_per_seg, (ch + 1u) * runs_per_chunk); r += NT) run_cls[(size_t)g * runs_per_seg + r] = 0xFFu;
+    for (uint32_t q = cs + t; q < cs + cn; q += NT) {
+      PktInfo pi = {};
+      pi.bad = 1;
+      pi.n = (uint16_t)H->bs[0];
+      info[sg.first_packet + q] = pi;
+      if (emit_len) emit_len[sg.first_packet + q] = 0;
+    }
+    if (t == 0 && last_chunk) sinfo[g] = SegInfo{0, 0, 0, 0};
+    return;
+  }
 
   // pass B
   {
@@ -303,58 +390,23 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     auto step_b = [&](uint32_t ql, const vsyn_packet& k) {  // ql: index inside the chunk
       const uint32_t q = cs + ql;
       const uint32_t p = sg.first_packet + q;
-      PktInfo pi = {};
       const bool mode_ok = k.mode < num_modes;
-      if (!mode_ok) raise_status(status, VSYN_ST_BAD_MODE, p);
       const uint32_t lng = mode_ok && s_bf[k.mode] ? 1u : 0u;
       const uint32_t n = lng ? bs1 : bs0;
-      const uint32_t L = prev_n ? prev_n / 4 + n / 4 : 0;
-      int64_t abs_after = abs_before + L;
-      uint32_t emit = L;
-      bool bad = !mode_ok;
-      if (k.granule >= 0) {
-        // hpp:1029 (position already past the page granule) and hpp:1041 (packets cannot reach it)
-        if (k.granule < abs_before || k.granule > abs_before + (int64_t)L) {
-          raise_status(status, VSYN_ST_GRANULE, p);
-          bad = true;
-          emit = 0;
-        } else {
-          emit = (uint32_t)(k.granule - abs_before);
-        }
-        abs_after = k.granule;
-      }
-      const int64_t rel = abs_before - abs0;
-      if (rel < 0 || (uint64_t)rel + emit > plane_stride) {
-        if (emit) raise_status(status, VSYN_ST_PLANE_OVERFLOW, p);
-        if (emit) bad = true;
-        emit = 0;
-      }
-      pi.res_off = res_off;
-      pi.out_pos = rel < 0 ? 0u : (uint32_t)rel;
-      pi.emit = emit;
-      pi.n = (uint16_t)n;
-      pi.lng = (uint8_t)lng;
-      pi.widx = lng ? (uint8_t)((k.prev_long ? 1 : 0) | (k.next_long ? 2 : 0)) : 0;
-      pi.mapping = mode_ok ? s_mm[k.mode] : 0;
-      pi.bad = bad ? 1 : 0;
-      const uint32_t chan_mask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
-      uint32_t own = k.floor_used & chan_mask, used = own;
-      const MapConst* mc = map_of(cb, pi.mapping);
-      for (uint32_t i = 0; i < mc->ncoup; ++i) {  // hpp:1175-1180
-        uint32_t m = mc->coup[2 * i], a = mc->coup[2 * i + 1];
-        if (((used >> m) | (used >> a)) & 1u) used |= (1u << m) | (1u << a);
-      }
-      pi.own = own;
-      pi.used = used;
-      info[p] = pi;
+      const PktStep ps = pkt_step(map_of(cb, 0), k, mode_ok, lng, mode_ok ? s_mm[k.mode] : 0u, n, prev_n, abs_before, abs0, res_off, plane_stride, C);
+      // (one flag at a time, in the order the checks are made: first_bad_packet is a minimum over packets, the flags an OR)
+      if (ps.raise & VSYN_ST_BAD_MODE) raise_status(status, VSYN_ST_BAD_MODE, p);
+      if (ps.raise & VSYN_ST_GRANULE) raise_status(status, VSYN_ST_GRANULE, p);
+      if (ps.raise & VSYN_ST_PLANE_OVERFLOW) raise_status(status, VSYN_ST_PLANE_OVERFLOW, p);
+      info[p] = ps.pi;
       if (mode_ok && lng) atomicOr(&s_longbits[(ql + 1u) >> 5], 1u << ((ql + 1u) & 31u));
       seg_of_pkt[p] = g;
-      if (emit_len) emit_len[p] = emit;
+      if (emit_len) emit_len[p] = ps.pi.emit;
       if (q == num - 1) {
-        s_abs_end = abs_after;
+        s_abs_end = ps.abs_after;
         s_last_n = n;
       }
-      abs_before = abs_after;
+      abs_before = ps.abs_after;
       res_off += (uint64_t)C * (n / 2);
       prev_n = n;
     };
@@ -398,7 +450,7 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     if (num == 0) {
       si.total_emit = 0;
       sinfo[g] = si;
-      if (reset) state[sg.stream] = StreamState{0, 0, 0, 0, 0};
+      if (reset) state_write(state, sg.stream, st_slot, StreamState{0, 0, 0, 0, 0}, epoch);
       return;
     }
     si.total_emit = (uint32_t)(s_abs_end - abs0);
@@ -408,8 +460,8 @@ vsyn_layout_kernel(const uint8_t* __restrict__ cb, uint32_t P, const vsyn_packet
     ns.has_prev = 1;
     ns.prev_n = s_last_n;
     ns.parity = si.parity_in ^ 1u;
-    ns.pad = 0;
-    state[sg.stream] = ns;
+    ns.tag = 0;
+    state_write(state, sg.stream, st_slot, ns, epoch);
   }
 }
 
@@ -469,8 +521,8 @@ vsyn_floor_unwrap_kernel(const uint8_t* __restrict__ cb, uint32_t P, const uint3
     // per-post constants are wave-uniform: read them through the scalar unit (constant address space -> s_load, scalar cache)
     // instead of 64 identical per-lane loads per post.
     const uint64_t fc_bits = (uint64_t)(uintptr_t)fc;
-    const uint64_t fc_first = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)fc_bits) |
-                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fc_bits >> 32)) << 32);
+    const uint64_t fc_first = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)fc_bits) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(fc_bits >> 32)) << 32);
     const bool fc_uniform = __all(fc_bits == fc_first);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) u32x4* const_pk;

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
     for nm in names:
         assert hasattr(lib, nm), nm
     assert sorted(binding.declared_symbols()) == names
-    assert lib.vsyn_abi_version() == 4
+    assert lib.vsyn_abi_version() == 5
     assert b"gfx950" in lib.vsyn_version()
 
 

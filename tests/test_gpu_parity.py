@@ -13,7 +13,7 @@ from tests.workloads import fixture_like_spec, load_golden, synth_batch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-PATHS = [0, binding.VSYN_SUBMIT_STAGED]
+PATHS = [0, binding.VSYN_SUBMIT_PRE_KERNELS, binding.VSYN_SUBMIT_STAGED]  # in-wave preparation (default), pre-kernels, staged kernels
 
 
 def bits(a):

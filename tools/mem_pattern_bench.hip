@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -257,7 +258,7 @@ static void run(const char* name, const float* in, float* out, uint32_t streams,
   printf("%-34s pace %4d: %.3f ms  %.2f TB/s (%s)\n", name, pace, best, bytes / best / 1e9, WRITE ? "read + write" : "read only");
 }
 
-int main() {
+int main(int argc, char** argv) {
   const uint32_t streams = 64, runs = 32, R = 32;
   const uint64_t plane = (uint64_t)runs * R * BLK + 64;
   const size_t n_in = (size_t)streams * runs * R * 2 * BLK, n_out = (size_t)streams * 2 * plane;
@@ -266,6 +267,18 @@ int main() {
   CHECK(hipMalloc((void**)&out, n_out * 4));
   CHECK(hipMemset(in, 0, n_in * 4));
   CHECK(hipMemset(out, 0, n_out * 4));
+  if (argc > 1) {
+    // counter mode (round 3): `mem_pattern_bench <run length>` launches ONLY the streaming pattern at that run length (same bytes, 32 / R
+    // times the waves) so that a `rocprofv3 --pmc TCC_EA0_RDREQ_DRAM_sum ...` pass sees one kernel shape; "flat" = the linear sweep
+    if (!strcmp(argv[1], "flat")) {
+      run<16, true, true, 3>("linear, 16 B/lane, nt both", in, out, streams, runs, R, plane, 0);
+      return 0;
+    }
+    const uint32_t r = (uint32_t)atoi(argv[1]);
+    if (r < 1 || r > 32 || (32 % r)) return 2;
+    run<8, false, true, 3>("runs of argv[1], nt both", in, out, streams, runs * (32 / r), r, plane, 0);
+    return 0;
+  }
   // cache policies spelled out (loads / stores): 0 default, 1 nt, 2 nt sc1, 3 sc0 sc1 nt, 4 sc1, 5 sc0
   run_pol<0, 0>("policy: default / default", in, out, streams, runs, R, plane);
   run_pol<1, 1>("policy: nt / nt", in, out, streams, runs, R, plane);

@@ -4,6 +4,7 @@
 // (hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory), and no cross-stream ordering at all (lower bound).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/stream_sync_bench tools/stream_sync_bench.hip
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -110,6 +111,70 @@ int main() {
     CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     timeit("captured graph, two steps per launch", [&](int n) {
       for (int i = 0; i < n; i += 2) CHECK(hipGraphLaunch(ge, M));
+    });
+  }
+  {
+    // round 3: ONE stream. The short kernel of step i+1 is launched behind the long kernel of step i with hipExtAnyOrderLaunch (no barrier
+    // bit on its dispatch packet: it need not wait for the long kernel), the next long kernel is an ordinary launch (waits for everything
+    // before it). No events, no second queue.
+    timeit("one stream, short kernel launched any-order", [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        hipExtLaunchKernelGGL(spin_kernel, dim3(64), dim3(64), 0, M, nullptr, nullptr, hipExtAnyOrderLaunch, SHORT_T, sink);
+        spin_kernel<<<256, 64, 0, M>>>(LONG_T, sink);
+      }
+    });
+    timeit("one stream, short kernel ordinary launch (serial)", [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        spin_kernel<<<64, 64, 0, M>>>(SHORT_T, sink);
+        spin_kernel<<<256, 64, 0, M>>>(LONG_T, sink);
+      }
+    });
+    // events attached to the kernels' own dispatch packets (stopEvent of hipExtLaunchKernelGGL) instead of hipEventRecord
+    const unsigned fl = hipEventDisableTiming | hipEventDisableSystemFence;
+    hipEvent_t pre_done[2], main_done[2];
+    for (int b = 0; b < 2; ++b) {
+      CHECK(hipEventCreateWithFlags(&pre_done[b], fl));
+      CHECK(hipEventCreateWithFlags(&main_done[b], fl));
+    }
+    bool valid[2] = {false, false};
+    timeit("events as the kernels' stopEvent (fence-free)", [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        const int b = i & 1;
+        if (valid[b]) CHECK(hipStreamWaitEvent(P, main_done[b], 0));
+        hipExtLaunchKernelGGL(spin_kernel, dim3(64), dim3(64), 0, P, nullptr, pre_done[b], 0, SHORT_T, sink);
+        CHECK(hipStreamWaitEvent(M, pre_done[b], 0));
+        hipExtLaunchKernelGGL(spin_kernel, dim3(256), dim3(64), 0, M, nullptr, main_done[b], 0, LONG_T, sink);
+        valid[b] = true;
+      }
+    });
+    // a ring of 4 workspaces: pre(i+1) only waits for main(i-3), so its event is long complete when main(i+1) is reached
+    hipEvent_t pd[4], md[4];
+    bool v4[4] = {false, false, false, false};
+    for (int b = 0; b < 4; ++b) {
+      CHECK(hipEventCreateWithFlags(&pd[b], fl));
+      CHECK(hipEventCreateWithFlags(&md[b], fl));
+    }
+    timeit("events, fence-free, ring of 4 (pre runs 3 steps ahead)", [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        const int b = i & 3;
+        if (v4[b]) CHECK(hipStreamWaitEvent(P, md[b], 0));
+        spin_kernel<<<64, 64, 0, P>>>(SHORT_T, sink);
+        CHECK(hipEventRecord(pd[b], P));
+        CHECK(hipStreamWaitEvent(M, pd[b], 0));
+        spin_kernel<<<256, 64, 0, M>>>(LONG_T, sink);
+        CHECK(hipEventRecord(md[b], M));
+        v4[b] = true;
+      }
+    });
+    // only the wait on M (no record on M at all: as if the workspace ring were deep enough never to need one)
+    timeit("events, fence-free, only pre_done (no record on M)", [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        const int b = i & 3;
+        spin_kernel<<<64, 64, 0, P>>>(SHORT_T, sink);
+        CHECK(hipEventRecord(pd[b], P));
+        CHECK(hipStreamWaitEvent(M, pd[b], 0));
+        spin_kernel<<<256, 64, 0, M>>>(LONG_T, sink);
+      }
     });
   }
   timeit("two streams, no ordering between them (lower bound)", [&](int n) {

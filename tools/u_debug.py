@@ -13,11 +13,12 @@ if set(pattern) <= set("01"):
 streams, npk = int(sys.argv[5]), int(sys.argv[6])
 seed = int(sys.argv[7]) if len(sys.argv) > 7 else 5
 spec = fixture_like_spec(C, bs0, bs1)
-b = synth_batch(spec, streams, npk, pattern, seed=seed)
+import os
+b = synth_batch(spec, streams, npk, pattern, seed=seed, unused_frac=float(os.environ.get("UNUSED", "0")), granule_last=bool(int(os.environ.get("GRANULE", "0"))))
 want = ob.OracleSynth(spec, streams).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
 gpu = binding.Synth(spec, max_streams=streams)
 print("fused_paths", gpu.fused_paths)
-got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=int(os.environ.get("FLAGS", "0")))
 print("rc", got["rc"], got["flags"], "emit equal", np.array_equal(got["emit_len"], want["emit_len"]))
 long_mode = [i for i, (bf, _) in enumerate(spec.modes) if bf][0]
 for s in range(streams):
