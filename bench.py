@@ -156,8 +156,8 @@ def run_config5(args, rank, world, local, device):
     gold = np.load(os.path.join(here, "tests", "golden", "test.stereo44khz.npz"))
     want_frames = int(gold["pcm"].shape[-1])  # the reference decoder's total for this file (granule-derived)
     n = args.files_per_gpu
-    cores = os.cpu_count() or 16
-    share = max(2, min(16, cores // max(1, world)))   # this rank's cores: one entropy worker each; the feeders mostly wait on the GPU
+    cores = len(RANK_CPUS) if world > 1 else (os.cpu_count() or 16)
+    share = max(2, min(16, cores if world > 1 else cores // max(1, world)))   # this rank's cores: one entropy worker each; the feeders mostly wait on the GPU
     feeders = args.feeders or (3 if share >= 12 else (2 if share >= 6 else 1))
     threads = args.host_threads or share
     datas = (C.c_char_p * n)(*([blob] * n))
@@ -216,10 +216,80 @@ def run_config5(args, rank, world, local, device):
                                          ", int16" if args.pcm_s16 else ", f32")},
                 "cpu_baseline": cpu,
                 "packets_per_s_per_host_thread": round(total * args.steps / dt / max(1, threads * world), 1),
+                "host_placement": {"rank0_cpus": _fmt_cpus(RANK_CPUS), "rank0_numa_node": RANK_NUMA, "pinned": world > 1,
+                                   "note": "every rank pins itself to its GPU's NUMA-local cores before the first GPU call (sysfs topology); "
+                                           "the whole-job rate is packets_per_s_per_host_thread x entropy threads per rank x ranks while the "
+                                           "host cores last"},
                 "realtime_factor": round(extra[2] * args.steps / dt / 44100.0, 1),
                 "entropy_cpu_s_per_step": round(extra[0] / world, 3), "gpu_call_s_per_step": round(extra[1] / world, 3),
                 "replicas_bit_identical": None if args.pcm_s16 else True, "frames_per_file": want_frames}
         print(json.dumps(line))
+
+
+RANK_CPUS, RANK_NUMA = [], None
+
+
+def _fmt_cpus(cpus):
+    """[0,1,2,3,8] -> '0-3,8'"""
+    out, i = [], 0
+    cpus = sorted(cpus)
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def _parse_cpulist(txt):
+    out = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def rank_cpu_set(local, local_world):
+    """The cores this rank's host threads (entropy workers, feeders, pinned-buffer first touch) should run on: the cores of the NUMA
+    node its GPU hangs off, shared evenly by the ranks whose GPUs sit on the same node; without topology information, an even
+    contiguous share of the cores the process may use. Read from sysfs only (KFD topology -> PCI address -> local_cpulist): no GPU
+    call is made, so this can run before anything initialises the device. -> (sorted core list, numa node or None)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if local_world <= 1:
+        return allowed, None
+    gpus = []  # (kfd node order) -> pci address
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for nd in sorted(os.listdir(base), key=int):
+            props = dict(l.split(None, 1) for l in open(os.path.join(base, nd, "properties")).read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0:
+                loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+                gpus.append("%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        if vis and all(v.strip().isdigit() for v in vis.split(",")):
+            gpus = [gpus[int(v)] for v in vis.split(",") if int(v) < len(gpus)]
+    except Exception:
+        gpus = []
+    node_of, cpus_of = {}, {}
+    for i, bdf in enumerate(gpus):
+        try:
+            node_of[i] = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+            cpus_of[i] = [c for c in _parse_cpulist(open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read()) if c in allowed]
+        except Exception:
+            pass
+    if local in cpus_of and cpus_of[local]:
+        peers = sorted(i for i in range(local_world) if node_of.get(i, -2) == node_of[local])  # ranks whose GPUs share the node
+        k, n = peers.index(local), len(peers)
+        cores = cpus_of[local]
+        per = max(1, len(cores) // n)
+        mine = cores[k * per:(k + 1) * per] if k < n - 1 else cores[k * per:]
+        if mine:
+            return mine, node_of[local]
+    per = max(1, len(allowed) // local_world)
+    return allowed[local * per:(local + 1) * per] or allowed, None
 
 
 def main():
@@ -252,15 +322,28 @@ def main():
     ap.add_argument("--no-steady", action="store_true", help="skip the longer run reported as steady_state beside a short timed region")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no HIP events around the dominant kernel (roofline.achieved is then null)")
+    ap.add_argument("--parity-gather", action="store_true",
+                    help="after the timed region: the small parity configuration of SURVEY 8e — every rank synthesises its share of a tiny "
+                         "seeded batch, the PCM is gathered over the process group (sharding.gather_pcm) and rank 0 checks every stream "
+                         "against the oracle")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not let a submit's pre-kernels overlap the previous submit (diagnostic: standalone kernel times)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rank-local host placement, before anything touches the GPU: this rank's threads (and the page-locked buffers they first touch)
+    # stay on the cores of its GPU's NUMA node. Matters for config 5, which is host-bound; harmless elsewhere.
+    global RANK_CPUS, RANK_NUMA
+    RANK_CPUS, RANK_NUMA = rank_cpu_set(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    if world > 1:
+        try:
+            os.sched_setaffinity(0, RANK_CPUS)
+        except OSError:
+            pass
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     # Rehearsal knobs for a ONE-GPU box (never set by the driver): BENCH_FORCE_DEVICE=0 puts every rank on that device and
     # BENCH_DIST_BACKEND=gloo carries the three tiny collectives (RCCL refuses two ranks on one GPU), so that the N > 1 code path
@@ -540,6 +623,33 @@ def main():
         cpu = {"value": round(4096 * reps / t_cpu, 1), "unit": "packets/s", "cores": 1, "kind": "port",
                "sample": "the same 4096 blocks, %d repetitions, %.1f s" % (reps, t_cpu)}
 
+    parity_gather = None
+    if args.parity_gather and b is not None:
+        # SURVEY 8e's small parity configuration: a tiny seeded corpus, its streams partitioned over the ranks exactly as the big
+        # batch is, synthesised on each rank's GPU, then ONE gather of the PCM over the process group (RCCL all_gather on GPUs; the
+        # one-GPU rehearsal carries it over gloo on host tensors) and rank 0 checks every stream of every rank against the oracle.
+        from tests.workloads import synth_batch
+        from oracle.oracle_binding import OracleSynth
+        ps_total, ps_ppk = 2 * world + 1, 14
+        small = synth_batch(spec, ps_total, ps_ppk, "mixed", seed=4242)  # the same corpus on every rank
+        first, count = sharding.shard_range(ps_total, rank, world)
+        sseg = small["segments"][first:first + count].copy()
+        sg = Synth(spec, device=local, max_streams=ps_total)
+        r = sg.submit_host(small["packets"], sseg, small["ys"], small["residue"], small["plane_stride"])
+        assert r["rc"] == 0, r["flags"]
+        frames = [int(r["emit_len"][int(x["first_packet"]):int(x["first_packet"]) + int(x["num_packets"])].sum()) for x in sseg]
+        gdev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+        pcm_all, frames_all = sharding.gather_pcm(r["pcm"], frames, gdev)
+        if rank == 0:
+            want = OracleSynth(spec, ps_total).submit_host(small["packets"], small["segments"], small["ys"], small["residue"], small["plane_stride"])
+            wf = [int(want["emit_len"][int(x["first_packet"]):int(x["first_packet"]) + int(x["num_packets"])].sum()) for x in small["segments"]]
+            assert list(frames_all) == wf, "gathered frame counts differ from the oracle's"
+            plane = min(pcm_all.shape[2], want["pcm"].shape[2])
+            gerr = float(np.abs(pcm_all[:, :, :plane] - want["pcm"][:, :, :plane]).max())
+            assert args.no_check or gerr < 1e-5, "gathered PCM max |err| vs oracle %.3g" % gerr
+            parity_gather = {"streams": int(pcm_all.shape[0]), "ranks": world, "max_abs_err_vs_oracle": gerr,
+                             "collective": "all_gather (%s)" % (dist.get_backend() if world > 1 else "single process")}
+
     pcm_stage = None
     if b is not None and args.pcm_s16 and rank == 0:
         # the post-stage on its own: same buffers, torch events on the launch stream
@@ -590,7 +700,7 @@ def main():
                          "algorithmic_bytes_per_packet": round(bytes_per_unit, 1)},
             "cpu_baseline": cpu, "pcm_stage_s16": pcm_stage,
             "pcm_max_abs_err_vs_oracle": max_err, "pcm_peak": None if max_err is None else pcm_peak,
-            "steady_state": steady,
+            "steady_state": steady, "parity_gather": parity_gather,
         }
         print(json.dumps(line))
     if world > 1:

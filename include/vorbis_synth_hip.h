@@ -144,10 +144,9 @@ typedef struct vsyn_handle vsyn_handle;
                                          pending on hip_stream). Lets the layout + floor-unwrap kernels of this submit overlap the
                                          synthesis kernel of the previous one; results are identical either way. */
 
-#define VSYN_SUBMIT_PRE_KERNELS 8u    /* diagnostics / A-B: prepare the batch (layout scan, floor-1 step 1) with the two chained kernels every
-                                         submit used before ABI 5 (with VSYN_SUBMIT_INPUTS_READY: on an internal stream, ordered by events).
-                                         Default: one dependency-free preparation kernel in front of the synthesis kernel on the caller's
-                                         stream whenever the fused kernels take the whole batch; results are identical either way. */
+#define VSYN_SUBMIT_PRE_KERNELS 8u    /* diagnostics / A-B: prepare the batch (layout scan, floor-1 step 1) with the two chained kernels also
+                                         where the single dependency-free preparation kernel would be used (submits without
+                                         VSYN_SUBMIT_INPUTS_READY whose runs are all taken by the fused kernels); results are identical. */
 #define VSYN_SUBMIT_KEEP_PCM 4u        /* vsyn_submit_host*: leave the PCM on the device (`pcm` may be NULL, nothing is copied back);
                                          fetch it in the form the consumer wants with vsyn_pcm_fetch_host */
 

@@ -639,9 +639,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   // floor curve and the unwrapped posts — do not force them: the posts come from the unwrap kernel either way and
   // the curve from the tap variant of the fused kernel.
   const bool want_taps = taps && (taps->after_envelope || taps->pcm_after_mdct);
-  // the size-generic kernel has no floor-curve tap: with that tap requested its runs go to the 256/2048 kernel's mixed path where
-  // that exists, to the staged kernels otherwise
-  const bool use_u = h->u_mixed && !(taps && taps->floor_curve);
+  const bool use_u = h->u_mixed;  // (both fused kernels have a floor-curve tap variant)
   const uint32_t fmask = use_u ? h->fused_mask : h->tuned_mask;
   const bool force_staged = want_taps || (flags & VSYN_SUBMIT_STAGED) || !fmask;
   const uint32_t R = force_staged ? std::min<uint32_t>(max_seg_packets, 1024u)
@@ -673,18 +671,24 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   uint32_t* segmap = h->ws_segmap[wb].p;
   uint32_t* list = h->ws_list[wb].p;
 
-  // Preparation of the batch (layout scan, floor-1 step 1).
-  //   WHAT: when every run is taken by a fused kernel and no segment is longer than PREP_MAX_SEG_PACKETS, ONE dependency-free kernel
-  //   (vsyn_prep.h). Otherwise (staged kernels, intermediate-signal taps, the residue VQ stage — its kernel needs the packets' offsets
-  //   first —, very long segments, VSYN_SUBMIT_PRE_KERNELS) the layout kernel and the unwrap kernel.
-  //   WHERE: with VSYN_SUBMIT_INPUTS_READY on the internal stream `pre`, ahead of the caller's stream (ordered by one event wait per
-  //   submit); otherwise in front of the synthesis kernel on the caller's stream.
+  // Preparation of the batch (layout scan, floor-1 step 1): two ways.
+  //   (a) With VSYN_SUBMIT_INPUTS_READY: the layout kernel and the unwrap kernel on the internal stream `pre`, beside the previous
+  //       submit's synthesis kernel — their ~35 us of dependent latency are hidden, at the price of one event record and one
+  //       cross-queue wait per submit (~15 us between two synthesis kernels) and ~6 us of interference with the synthesis grid.
+  //   (b) Otherwise, when every run is taken by a fused kernel and no segment is longer than PREP_MAX_SEG_PACKETS: ONE
+  //       dependency-free kernel (vsyn_prep.h, ~20 us) in front of the synthesis kernel on the caller's stream; no second queue, no
+  //       events. Else (staged kernels, intermediate-signal taps, the residue VQ stage — its kernel needs the packets' offsets first —,
+  //       very long segments, VSYN_SUBMIT_PRE_KERNELS) the layout and unwrap kernels there.
+  //   Round 3 measured (b) for device-resident pipelines too (VSYN_PREP_SERIAL=1): config 3 0.2592 vs 0.2586 ms per step, config 4
+  //   0.0877 vs 0.0860, 128/1024 0.226 vs 0.200 — the hidden pre-kernels win or tie everywhere, so (a) stays the default there; and
+  //   the preparation kernel on the internal stream (VSYN_PREP_OVERLAP=1): 0.266 ms, its 256-thread / 121-VGPR workgroups cost the
+  //   exact-fit synthesis grid more than the two small kernels do. (b) is what the host-buffer entry points get: 20 instead of ~35 us.
   static const bool env_no_prep_kernel = getenv("VSYN_NO_PREP_KERNEL") && atoi(getenv("VSYN_NO_PREP_KERNEL"));
+  static const bool env_prep_serial = getenv("VSYN_PREP_SERIAL") && atoi(getenv("VSYN_PREP_SERIAL"));
   static const bool env_prep_overlap = getenv("VSYN_PREP_OVERLAP") && atoi(getenv("VSYN_PREP_OVERLAP"));
-  const bool prep_kernel = !force_staged && (fmask & 2u) && !d_vq && max_seg_packets <= PREP_MAX_SEG_PACKETS && !(flags & VSYN_SUBMIT_PRE_KERNELS) && !env_no_prep_kernel;
-  // (the preparation kernel stays on the caller's stream: beside an exact-fit synthesis grid its workgroups cost the synthesis
-  // kernel more than the kernel takes alone — measured 0.254 vs 0.235 ms on config 3; VSYN_PREP_OVERLAP=1 for the A/B)
-  const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged && (!prep_kernel || env_prep_overlap);
+  const bool prep_ok = !force_staged && (fmask & 2u) && !d_vq && max_seg_packets <= PREP_MAX_SEG_PACKETS && !(flags & VSYN_SUBMIT_PRE_KERNELS) && !env_no_prep_kernel;
+  const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged && !(env_prep_serial && prep_ok);
+  const bool prep_kernel = prep_ok && (!overlap_pre || env_prep_overlap);
   hipStream_t ps = overlap_pre ? h->pre : s;
   if (ps != s) {
     // the slot's previous user, submit isub - WS_RING, has to be done: the first ring event recorded at or behind it says so
@@ -858,7 +862,7 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     if (use_u) {
       FusedArgs au = a;
       au.fused_ok = fmask;
-      if (time_u && (h->profile_which == 1 || h->profile_which == 2)) HIPCHK(profile_begin(h, s, "vsyn_fused_u_kernel"));
+      if (time_u && (h->profile_which == 1 || h->profile_which == 2)) HIPCHK(profile_begin(h, s, au.curve ? "vsyn_fused_u_tap_kernel" : "vsyn_fused_u_kernel"));
       e = u_launch(H, h->utab, au, s);
       if (e != hipSuccess) return fail(err, VSYN_ERR_HIP, "generic fused launch failed: %s", hipGetErrorString(e));
       if (time_u && (h->profile_which == 1 || h->profile_which == 2)) HIPCHK(profile_end(h, s));

@@ -121,7 +121,7 @@ struct UPass {
   bool valid, after_bad;  // after_bad: an invalid packet was skipped in front of this pass (the overlap chain restarts)
 };
 
-template <int ROLE, int UNS>
+template <int ROLE, int UNS, bool TAPC>
 __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, uint8_t* wmem, const uint8_t* pmem, const uint32_t wave_bytes, const uint32_t lane,
                                       const uint32_t g, const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C,
                                       const uint32_t c) {
@@ -394,6 +394,9 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
             const u_f32x2 e1 = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * (two >> 8));
             const uint32_t i0 = (uint32_t)__builtin_fmaf((float)(2u * k), e0.x, e0.y), i1 = (uint32_t)__builtin_fmaf((float)(2u * k + 1u), e1.x, e1.y);
             rb[u][t] = f2(rb[u][t].x * T.invdb[i0], rb[u][t].y * T.invdb[i1]);
+            if (TAPC && !nocurve) {  // feature tap "floor1 floor" (hpp:585): the table indices are the rendered curve; packed like the residue
+              ((uint32_t*)(A.curve + roff + (size_t)c * Mb))[k] = i0 | (i1 << 16);
+            }
           }
       }
       // ---- IMDCT: mirror element (set NS-1-u, register 7-t, lane 63-l), pre-rotation, radix-NS across the sets, NS x FFT-512 ----
@@ -697,12 +700,18 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 #pragma unroll
           for (int e = 0; e < 4; ++e) en[e] = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * ((w >> (8 * e)) & 0xFFu));
           u_f32x4 fl;
+          uint32_t cix[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const uint32_t ix = (uint32_t)__builtin_fmaf((float)(4u * lane + 256u * i + e), en[e].x, en[e].y);
             fl[e] = T.invdb[ix];
+            cix[e] = ix;
           }
           *(u_lds_f32x4*)(lds_f32*)(stage + j * M + 4u * lane + 256u * i) = fl;
+          if (TAPC && !nocurve) {  // feature tap "floor1 floor" (hpp:585): four consecutive bins of packet j, 8 bytes per lane
+            const uint64_t roff = ((uint64_t)pinf[8u * j + 1u] << 32) | pinf[8u * j];
+            *(uint2*)(A.curve + roff + (size_t)c * M + 4u * lane + 256u * i) = make_uint2(cix[0] | (cix[1] << 16), cix[2] | (cix[3] << 16));
+          }
         }
       }
     }
@@ -959,8 +968,8 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 
 // grid: groups of WPB = blockDim.x / 64 units (segment, run, channel), flattened as in vsyn_fused_kernel; the channels of a run are
 // adjacent waves of one workgroup. Takes every run of class 2 (with the tuned long-run kernel absent: every run).
-template <int UNS>
-__global__ void __launch_bounds__(UNS == 1 ? U_MAX_THREADS : 512) vsyn_fused_u_kernel(const UArgs U) {
+template <int UNS, bool TAPC>
+__device__ __forceinline__ void u_kernel_body(const UArgs& U) {
   extern __shared__ __attribute__((aligned(16))) uint8_t u_lds[];
   const FusedArgs& A = U.f;
   const ConstHeader* H = hdr_of(A.cb);
@@ -1000,11 +1009,18 @@ __global__ void __launch_bounds__(UNS == 1 ? U_MAX_THREADS : 512) vsyn_fused_u_k
   const int role = U.role_mode == 3 ? 3 : ((U.role_mode == 0 || C < 2) ? 0 : (c == mag ? 1 : 2));
   const uint32_t pw = (role == 1 || role == 2) ? (wave ^ 1u) : wave;
   const uint8_t* pmem = u_lds + U.table_bytes + pw * U.wave_bytes;
-  if (role == 0) u_run<0, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
-  else if (role == 1) u_run<1, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
-  else if (role == 2) u_run<2, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
-  else u_run<3, UNS>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  if (role == 0) u_run<0, UNS, TAPC>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else if (role == 1) u_run<1, UNS, TAPC>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else if (role == 2) u_run<2, UNS, TAPC>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
+  else u_run<3, UNS, TAPC>(A, T, wmem, pmem, U.wave_bytes, lane, g, sg, si, qa, qb, C, c);
 }
+
+template <int UNS>
+__global__ void __launch_bounds__(UNS == 1 ? U_MAX_THREADS : 512) vsyn_fused_u_kernel(const UArgs U) { u_kernel_body<UNS, false>(U); }
+// the same kernel with the "floor1 floor" feature tap (returnn_import.py:74-115 builds its features from that curve for
+// ANY file, so every block-size pair has the tap on its fast path) written on the way — its own launch, as in vsyn_fused.h
+template <int UNS>
+__global__ void __launch_bounds__(UNS == 1 ? U_MAX_THREADS : 512) vsyn_fused_u_tap_kernel(const UArgs U) { u_kernel_body<UNS, true>(U); }
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1136,6 +1152,10 @@ static inline hipError_t u_tables_create(const ConstHeader& H, const uint8_t* ho
   // (the attribute belongs to the kernel, not to the handle: one fixed value — the planning budget above — for every handle, so that a
   // later handle with a smaller LDS block never lowers the limit under an earlier one's launches)
   e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+  if (e == hipSuccess) {
+    const void* kft = ns == 1 ? (const void*)vsyn_fused_u_tap_kernel<1> : (ns == 2 ? (const void*)vsyn_fused_u_tap_kernel<2> : (const void*)vsyn_fused_u_tap_kernel<4>);
+    e = hipFuncSetAttribute(kft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+  }
   if (e != hipSuccess && getenv("VSYN_DEBUG"))
     fprintf(stderr, "vsyn: hipFuncSetAttribute(%u B dynamic LDS) failed: %s\n", budget, hipGetErrorString(e));
   return e == hipSuccess ? hipSuccess : hipErrorInvalidValue;
@@ -1158,7 +1178,11 @@ static inline hipError_t u_launch(const ConstHeader& H, const UTables& ut, const
   const uint32_t wpb = ut.waves_per_block;
   dim3 grid((uint32_t)((units + wpb - 1) / wpb));
   const size_t lds = ut.table_bytes + (size_t)wpb * ut.wave_bytes;
-  if (ut.ns == 1) vsyn_fused_u_kernel<1><<<grid, wpb * 64, lds, s>>>(u);
+  if (a.curve) {
+    if (ut.ns == 1) vsyn_fused_u_tap_kernel<1><<<grid, wpb * 64, lds, s>>>(u);
+    else if (ut.ns == 2) vsyn_fused_u_tap_kernel<2><<<grid, wpb * 64, lds, s>>>(u);
+    else vsyn_fused_u_tap_kernel<4><<<grid, wpb * 64, lds, s>>>(u);
+  } else if (ut.ns == 1) vsyn_fused_u_kernel<1><<<grid, wpb * 64, lds, s>>>(u);
   else if (ut.ns == 2) vsyn_fused_u_kernel<2><<<grid, wpb * 64, lds, s>>>(u);
   else vsyn_fused_u_kernel<4><<<grid, wpb * 64, lds, s>>>(u);
   return hipGetLastError();

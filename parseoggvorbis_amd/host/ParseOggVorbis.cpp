@@ -1052,13 +1052,16 @@ OkOrError VorbisStream::parse_audio(const uint8_t* data, uint32_t len, int64_t g
     if (vq_mode_) CHECK_ERR(res.decode_entries(reader, setup.codebooks, (uint32_t)outs.size(), ch_used, n2, cls_, entries_));
     else CHECK_ERR(res.decode(reader, setup.codebooks, (uint32_t)outs.size(), ch_used, n2, outs.data()));
   }
+#ifdef PARSEOGGVORBIS_TESTING
   {
-    // fault injection for the tests (tests/test_host_decoder.py): the k-th audio packet of every stream fails HERE, after its floor
-    // rows and residue have been appended — the worst place for the batch bookkeeping (a lookup-type-0 book in a residue, a floor-0
-    // submap or a partition overshoot fail at the same depth, but no fixture holds one)
+    // Fault injection, compiled into the TESTING build of the library only (libparseoggvorbis_amd_testing.so, host/Makefile; the
+    // product library holds none of this): the k-th audio packet of every stream fails HERE, after its floor rows and residue have
+    // been appended — the worst place for the batch bookkeeping (a lookup-type-0 book in a residue, a floor-0 submap or a partition
+    // overshoot fail at the same depth, but no fixture holds one).
     static const long fail_at = getenv("PARSEOGGVORBIS_TEST_FAIL_AT") ? atol(getenv("PARSEOGGVORBIS_TEST_FAIL_AT")) : -1;
     if (fail_at >= 0 && (long)(packets_seen_++) == fail_at) CHECK(false && "injected failure (PARSEOGGVORBIS_TEST_FAIL_AT)");
   }
+#endif
   if (vq_mode_) {
     vqp.num_entries = (uint32_t)(entries_.size() - vqp.entry_off);
     vq_pk_.push_back(vqp);
@@ -1108,7 +1111,19 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
     first_batch_ = false;
     return sink_->consume(*this, std::move(b));
   }
-  if (!synth_) CHECK_ERR(make_synth(*this));  // the GPU handle is created when the first batch is ready
+  // A hard failure of the GPU layer below drops the batch: the reader's error path flushes every stream once more so that packets in
+  // front of a PARSE error are still delivered (hpp:1045-1054) — after a failure in here that second flush must find nothing to resubmit.
+  auto drop_batch = [this]() {
+    pk_.clear(); ys_.clear(); residue_.clear(); floor_number_.clear(); vq_pk_.clear(); cls_.clear(); entries_.clear();
+    residue_floats_ = 0;
+  };
+  if (!synth_) {  // the GPU handle is created when the first batch is ready
+    OkOrError e = make_synth(*this);
+    if (e.is_error_) {
+      drop_batch();
+      return e;
+    }
+  }
   const uint32_t C = header.audio_channels, P = (uint32_t)pk_.size();
   const uint32_t bs0 = header.get_blocksize_0(), bs1 = header.get_blocksize_1();
   const uint64_t plane = (uint64_t)P * (bs1 / 2);
@@ -1152,7 +1167,10 @@ OkOrError VorbisStream::flush(ParseCallbacks& cb) {
     rc = vsyn_submit_host(synth_, P, pk_.data(), 1, &seg, ys_.data(), residue_.data(), residue_.size(), pcm.data(), plane, emit.data(),
                           hooks ? &taps : nullptr, 0, &st, &err);
   }
-  if (rc != VSYN_OK && rc != VSYN_ERR_STREAM) return OkOrError(std::string("GPU synthesis layer: ") + (err ? err : "submit failed"));
+  if (rc != VSYN_OK && rc != VSYN_ERR_STREAM) {
+    drop_batch();
+    return OkOrError(std::string("GPU synthesis layer: ") + (err ? err : "submit failed"));
+  }
   const uint32_t good = rc == VSYN_ERR_STREAM ? std::min(P, st.first_bad_packet) : P;
 
   // replay, packet by packet, exactly the entries upstream pushes between hpp:1139 and hpp:1271

@@ -1,6 +1,7 @@
 """Multi-GPU plumbing of the path: one process per GPU, streams partitioned across ranks, no data-path collective
 (all synthesis state is per stream, reference hpp:1117-1123).  Collectives used: ONE broadcast of the stream setup
-(the job split) and scalar all-reduces of clock / counters; PCM stays where it was produced.  Backend-agnostic:
+(the job split) and scalar all-reduces of clock / counters; PCM stays where it was produced in the throughput configurations and
+is gathered (gather_pcm: two all_gathers) only in the small parity configuration.  Backend-agnostic:
 "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  torch.distributed is plumbing here, not the product.
 """
 import numpy as np
@@ -129,3 +130,41 @@ def aggregate(dt_seconds, units, device, extra_sum=()):
     s = torch.tensor([float(units)] + [float(x) for x in extra_sum], dtype=torch.float64, device=device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t.item()), int(round(s[0].item())), tuple(float(x) for x in s[1:])
+
+
+def gather_pcm(pcm, frames, device):
+    """The parity configuration's PCM gather ("ncclAllGather/gatherv of PCM only in the small parity config").
+    pcm: this rank's planar PCM [S_local][C][plane] (numpy or torch, float32); frames: emitted frames per local stream [S_local].
+    Two collectives: an all_gather of the per-rank shapes (stream count, plane length) and stream frame counts, then an
+    all_gather of the PCM padded to the largest (streams x plane) of any rank — the gatherv. Every rank returns
+    (pcm_all [S_total][C][max plane], frames_all [S_total]) with the ranks' streams in rank order, i.e. in shard_range order.
+    Without an initialised group (or world size 1): the inputs, unchanged in content."""
+    import torch
+    import torch.distributed as dist
+    pcm_t = torch.as_tensor(np.ascontiguousarray(pcm) if isinstance(pcm, np.ndarray) else pcm, dtype=torch.float32)
+    fr_t = torch.as_tensor(np.asarray(frames, np.int64))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return pcm_t.cpu().numpy(), fr_t.cpu().numpy()
+    world = dist.get_world_size()
+    S, C, plane = (int(x) for x in pcm_t.shape) if pcm_t.numel() or pcm_t.dim() == 3 else (0, 0, 0)
+    shape = torch.tensor([S, C, plane], dtype=torch.int64, device=device)
+    shapes = [torch.zeros(3, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(shapes, shape)
+    shapes = [[int(v) for v in t.cpu()] for t in shapes]
+    max_s = max(sh[0] for sh in shapes)
+    max_plane = max(sh[2] for sh in shapes)
+    chans = max(sh[1] for sh in shapes)
+    assert all(sh[1] in (0, chans) for sh in shapes), "ranks disagree on the channel count"
+    # frame counts and PCM, padded to the largest shard (all_gather needs equal shapes on every rank)
+    fpad = torch.zeros(max(max_s, 1), dtype=torch.int64, device=device)
+    fpad[:S] = fr_t.to(device)
+    fall = [torch.zeros_like(fpad) for _ in range(world)]
+    dist.all_gather(fall, fpad)
+    ppad = torch.zeros((max(max_s, 1), max(chans, 1), max(max_plane, 1)), dtype=torch.float32, device=device)
+    if S:
+        ppad[:S, :, :plane] = pcm_t.to(device)
+    pall = [torch.zeros_like(ppad) for _ in range(world)]
+    dist.all_gather(pall, ppad)
+    pcm_all = torch.cat([pall[r][:shapes[r][0]] for r in range(world)], dim=0)
+    frames_all = torch.cat([fall[r][:shapes[r][0]] for r in range(world)], dim=0)
+    return pcm_all.cpu().numpy(), frames_all.cpu().numpy()

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "parseoggvorbis_amd", "host")
 CLI = os.path.join(HOST, "ours_hip.bin")
+CLI_TESTING = os.path.join(HOST, "ours_hip_testing.bin")  # the same CLI over the TESTING build of the library (fault injection)
 TOL = 1e-5
 INVDB = np.ctypeslib.as_array(__import__("oracle.oracle_binding", fromlist=["x"]).oracle().orc_inverse_db_table(), (256,)).copy()
 
@@ -319,8 +320,11 @@ def test_error_in_mid_stream_still_delivers_the_packets_before_it(vq, tmp_path):
     spec, b, z = load_golden(name)
     dump = str(tmp_path / "d.bin")
     env = dict(os.environ, PARSEOGGVORBIS_TEST_FAIL_AT=str(k), PARSEOGGVORBIS_VQ=vq)
-    r = subprocess.run([CLI, "--in", os.path.join(GOLDEN, name + ".ogg"), "--debug_out", dump], capture_output=True, text=True, env=env)
+    r = subprocess.run([CLI_TESTING, "--in", os.path.join(GOLDEN, name + ".ogg"), "--debug_out", dump], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "injected failure" in (r.stdout + r.stderr)
+    # the product build holds no fault injection: the same variable changes nothing there
+    r2 = subprocess.run([CLI, "--in", os.path.join(GOLDEN, name + ".ogg")], capture_output=True, text=True, env=env)
+    assert r2.returncode == 0, r2.stderr[-500:]
     header, entries = read_dump(dump)
     setup, packets, pcm = split_packets(entries, spec.channels)
     assert len(packets) == k

@@ -33,8 +33,10 @@ def _run(extra):
 
 
 def test_two_ranks_default_workload():
-    j = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline"])
+    j = _run(["--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--parity-gather"])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["packets_per_gpu"] == 65536
+    # the parity configuration's PCM gather: both ranks' streams, gathered over the process group, equal the oracle's
+    assert j["parity_gather"]["streams"] == 5 and j["parity_gather"]["ranks"] == 2 and j["parity_gather"]["max_abs_err_vs_oracle"] < 1e-5
     # whole-job aggregate: both ranks' packets over the slower rank's clock
     assert abs(j["value"] - 2 * 65536 * 20 / (j["ms_per_step"] * 1e-3 * 20)) / j["value"] < 0.01
     assert j["pcm_max_abs_err_vs_oracle"] is not None and j["pcm_max_abs_err_vs_oracle"] < 1e-5
@@ -43,3 +45,4 @@ def test_two_ranks_default_workload():
 def test_two_ranks_real_files():
     j = _run(["--steps", "1", "--warmup", "1", "--workload", "config5", "--files-per-gpu", "200", "--host-threads", "4"])
     assert j["n_gpus"] == 2 and j["config"]["packets_per_gpu"] == 200 * 94 and j["replicas_bit_identical"]
+    assert j["host_placement"]["pinned"] and j["host_placement"]["rank0_cpus"]  # every rank pinned itself to its share of the cores

@@ -345,15 +345,20 @@ def test_garbage_descriptors_and_posts(flags):
         orc = ob.OracleSynth(spec, 3)
 
 
-@pytest.mark.parametrize("pattern,C", [("long", 2), ("mixed", 2), ("mixed", 1)])
-def test_feature_taps_from_the_fused_kernel(pattern, C):
-    """the feature taps alone ("floor1 floor" curve + unwrapped posts) do not leave the fast path — the tap variant
-    of the fused kernel writes the curve on the way. Curve and posts equal the oracle's (integers: exact), PCM as without taps,
-    and the staged kernels produce the very same tap."""
-    spec = fixture_like_spec(C)
+@pytest.mark.parametrize("pattern,C,bs0,bs1", [("long", 2, 256, 2048), ("mixed", 2, 256, 2048), ("mixed", 1, 256, 2048),
+                                               ("mixed", 2, 128, 1024), ("long", 2, 128, 1024), ("mixed", 3, 128, 1024),   # size-generic kernel
+                                               ("mixed", 2, 512, 4096), ("mixed", 1, 64, 8192), ("mixed", 2, 1024, 2048)])  # ... its register sets; both kernels
+def test_feature_taps_from_the_fused_kernel(pattern, C, bs0, bs1):
+    """the feature taps alone ("floor1 floor" curve + unwrapped posts) do not leave the fast path, whatever the block
+    sizes (returnn_import.py:74-115 extracts them from any file) — the tap variants of the fused kernels write the curve on the way.
+    Curve and posts equal the oracle's (integers: exact), PCM as without taps, and the staged kernels produce the very same tap."""
+    spec = fixture_like_spec(C, bs0, bs1)
+    if C > 2:  # (a coupling list for three channels)
+        spec = SetupSpec(C, bs0, bs1, spec.floors, [([(0, 1), (0, 2)], [0] * C), ([(0, 1), (0, 2)], [1] * C)], [(0, 0), (1, 1)])
     b = synth_batch(spec, 4, 45, pattern, seed=31, unused_frac=0.15, granule_last=True)
     want = ob.OracleSynth(spec, 4).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
     gpu = binding.Synth(spec, max_streams=4)
+    assert gpu.fused_paths & 2, gpu.fused_paths  # every run of this setup is taken by a fused kernel
     got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps="features")
     check(got, want)
     assert np.array_equal(got["taps"]["floor_curve"], want["taps"]["floor_curve"])
@@ -505,3 +510,51 @@ def test_multichannel_and_chained_couplings_stay_fused(C, bs0, bs1, coup):
     gpu.reset()
     staged = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED)
     check(staged, want)
+
+
+MIXED_MAPPINGS = [
+    # C, bs0, bs1, couplings of mapping 0 (short-block mode), couplings of mapping 1 (long-block mode)
+    (2, 128, 1024, [], [(0, 1)]),                      # the shape of round 2's hang: an uncoupled mapping beside a coupled one
+    (2, 256, 2048, [(0, 1)], []),                      # 256/2048 with mappings that disagree: not the tuned kernel's pairwise swap
+    (3, 256, 1024, [], [(0, 1), (0, 2)]),
+    (4, 128, 512, [(0, 1), (2, 3)], [(2, 3)]),
+]
+
+
+@pytest.mark.parametrize("C,bs0,bs1,coup0,coup1", MIXED_MAPPINGS)
+def test_mappings_with_different_coupling_lists_stay_fused(C, bs0, bs1, coup0, coup1):
+    """The mappings of one stream carry DIFFERENT coupling lists, one of them empty (hpp:765-814): passes of the uncoupled mapping
+    take no part in the channel-group hand-off of the size-generic kernel, whose wait target therefore counts coupled passes only
+    (round 2: a counter that counted every pass hung the kernel). Run class asserted; PCM against the oracle, fused == staged."""
+    base = fixture_like_spec(1, bs0, bs1)
+    spec = SetupSpec(C, bs0, bs1, base.floors, [(coup0, [0] * C), (coup1, [1] * C)], [(0, 0), (1, 1)])
+    b = synth_batch(spec, 3, 37, "mixed", seed=C * 7 + bs1, unused_frac=0.2, granule_last=True)
+    gpu = binding.Synth(spec, max_streams=3)
+    assert gpu.fused_paths & 2, gpu.fused_paths
+    want = ob.OracleSynth(spec, 3).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    for flags in (0, binding.VSYN_SUBMIT_PRE_KERNELS, binding.VSYN_SUBMIT_STAGED):
+        gpu.reset()
+        got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=flags)
+        check(got, want)
+
+
+@pytest.mark.parametrize("streams,npk", [(1, 10007), (2, 9000)])
+def test_chunked_layout_scan_twice_on_one_handle(streams, npk):
+    """Segments beyond LAYOUT_CHUNK_PACKETS (4096): the layout kernel scans them in chunks chained by a look-back whose records are
+    tagged with the submit number and never cleared — so the SAME handle runs the batch twice (the second run meets the first run's
+    records). Mixed blocks, page granules inside the stream; emit_len and PCM against the oracle both times."""
+    from parseoggvorbis_amd import sharding
+    spec = fixture_like_spec(2)
+    b = synth_batch(spec, streams, npk, "mixed", seed=npk, granule_last=True)
+    for s in range(streams):  # page granules mid-stream (every 9th packet ends a page), consistent with the block sizes
+        pk = b["packets"][s * npk:(s + 1) * npk]
+        abs_before, emit = sharding.stream_positions(spec, pk)
+        for q in range(8, npk - 1, 9):
+            pk["granule"][q] = int(abs_before[q] + emit[q])
+    want = ob.OracleSynth(spec, streams).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert want["rc"] == 0
+    gpu = binding.Synth(spec, max_streams=streams)
+    for rep in range(2):
+        gpu.reset()
+        got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+        check(got, want)

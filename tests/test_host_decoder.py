@@ -274,8 +274,10 @@ def test_packet_that_fails_half_way_leaves_the_batch_consistent(probe, tmp_path,
 
     # deterministic first: the 20th audio packet fails after its floor rows and residue were appended (fault injection in
     # VorbisStream::parse_audio) — the reader must deliver exactly the 20 packets in front of it, consistently
+    from tests.workloads import build_probe
+    probe_t = build_probe(tmp_path, testing=True)  # (the fault injection exists in the TESTING build of the library only)
     for name, want in (("test.stereo44khz", 20), ("test.mono44khz", 7)):
-        r = subprocess.run([probe, "--check", os.path.join(GOLDEN, name + ".ogg")], capture_output=True, text=True,
+        r = subprocess.run([probe_t, "--check", os.path.join(GOLDEN, name + ".ogg")], capture_output=True, text=True,
                            env=dict(os.environ, PARSEOGGVORBIS_VQ=vq, PARSEOGGVORBIS_TEST_FAIL_AT=str(want)))
         assert r.returncode == 0 and r.stdout.startswith("consistent batches=1 packets=%d error=1" % want), (r.returncode, r.stdout, r.stderr[-300:])
     rng = np.random.default_rng(77)

@@ -1,5 +1,5 @@
 """N > 1 path on CPU: two gloo ranks exercise the sharding plumbing bench.py uses on GPUs (setup broadcast from rank 0,
-stream partition, scalar aggregation) and check that sharded synthesis == unsharded synthesis, stream for stream
+stream partition, scalar aggregation, the parity configuration's PCM gather) and check that sharded synthesis == unsharded synthesis, stream for stream
 (the oracle stands in for the GPU here: the point is the partitioning, not the arithmetic)."""
 import os
 import socket
@@ -42,7 +42,11 @@ def _worker(rank, world, port, out_dir):
         emitted = int(r["emit_len"].sum())
         dt, units, (samples,) = sharding.aggregate(0.5 + rank, count * PPK, dev, extra_sum=(emitted,))
         assert dt == pytest.approx(0.5 + world - 1) and units == STREAMS * PPK
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), first=first, count=count, pcm=r["pcm"], samples=samples)
+        # the parity configuration's PCM gather: every rank ends up with every stream's PCM, in stream order
+        frames = [int(r["emit_len"][int(sg["first_packet"]):int(sg["first_packet"]) + int(sg["num_packets"])].sum()) for sg in seg]
+        pcm_all, frames_all = sharding.gather_pcm(r["pcm"], frames, dev)
+        assert pcm_all.shape[0] == STREAMS and int(frames_all.sum()) == int(samples)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), first=first, count=count, samples=samples, pcm_all=pcm_all, frames_all=frames_all)
     finally:
         dist.destroy_process_group()
 
@@ -55,11 +59,17 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     full = synth_batch(spec, STREAMS, PPK, "mixed", seed=77)
     want = OracleSynth(spec, STREAMS).submit_host(full["packets"], full["segments"], full["ys"], full["residue"], full["plane_stride"])
     covered = []
+    want_frames = [int(want["emit_len"][int(sg["first_packet"]):int(sg["first_packet"]) + int(sg["num_packets"])].sum()) for sg in full["segments"]]
     for rank in range(world):
         z = np.load(tmp_path / ("rank%d.npz" % rank))
         first, count = int(z["first"]), int(z["count"])
         covered += list(range(first, first + count))
-        assert np.array_equal(z["pcm"], want["pcm"][first:first + count])  # a rank's streams do not depend on the others
+        # what EVERY rank holds after the gather: all streams, bit for bit what one process computes (a rank's streams do not depend
+        # on the others), with the frame counts that say how much of each plane is PCM
+        assert list(z["frames_all"]) == want_frames
+        plane = min(z["pcm_all"].shape[2], want["pcm"].shape[2])
+        assert np.array_equal(z["pcm_all"][:, :, :plane].view(np.uint32), want["pcm"][:, :, :plane].view(np.uint32))
+        assert not z["pcm_all"][:, :, plane:].any()
         assert int(z["samples"]) == int(want["emit_len"].sum())            # all-reduced total
     assert covered == list(range(STREAMS))
 

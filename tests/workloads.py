@@ -219,15 +219,16 @@ def read_entropy_dump(path):
     return d
 
 
-def build_probe(tmpdir):
-    """Compile tests/host_entropy_dump.cpp against the built host library; returns the executable's path."""
+def build_probe(tmpdir, testing=False):
+    """Compile tests/host_entropy_dump.cpp against the built host library (testing: the build with the fault injection of
+    PARSEOGGVORBIS_TEST_FAIL_AT compiled in); returns the executable's path."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     host = os.path.join(root, "parseoggvorbis_amd", "host")
     csrc = os.path.join(root, "parseoggvorbis_amd", "csrc")
-    out = os.path.join(str(tmpdir), "host_entropy_dump")
+    out = os.path.join(str(tmpdir), "host_entropy_dump" + ("_testing" if testing else ""))
     subprocess.run(["g++", "-std=c++17", "-O2", "-o", out, os.path.join(root, "tests", "host_entropy_dump.cpp"),
-                    "-L" + host, "-lparseoggvorbis_amd", "-L" + csrc, "-lvorbis_synth_hip", "-Wl,-rpath," + host,
+                    "-L" + host, "-lparseoggvorbis_amd" + ("_testing" if testing else ""), "-L" + csrc, "-lvorbis_synth_hip", "-Wl,-rpath," + host,
                     "-Wl,-rpath," + csrc, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
     return out
 
