@@ -643,8 +643,9 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
   // look-ahead, and without one every long block of a mixed run waited a full memory latency.
   bool dma_ahead = false;     // this packet's rows are already in flight towards (or in) the image
   uint32_t dma_younger = 0;   // vector-memory operations issued behind that request: 8 = exactly the fast path's PCM stores
-  auto issue_dma = [&](uint64_t off) {
-    const char* gsrc = (const char*)(A.residue + off) + 16u * lane0;
+  auto issue_dma = [&](uint64_t off, const uint32_t ln) {  // ln: the laundered lane number of the iteration (a pointer built from
+                                                           // lane0 is hoisted out of the packet loop and ends up spilled)
+    const char* gsrc = (const char*)(A.residue + off) + 16u * ln;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + 1024 * i),
@@ -712,7 +713,11 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
     }
     if (pi.mapping != cur_map) {  // wave-uniform, rare
       cur_map = pi.mapping;
-      map_floor = __builtin_amdgcn_readfirstlane((uint32_t)maps[cur_map].chfloor[c]);
+      {  // (through the scalar unit: one dword of the channel -> floor bytes; a per-lane byte load keeps its address pair in VGPRs)
+        typedef const __attribute__((address_space(4))) uint32_t* kptr;
+        const uint32_t w = *(kptr)(uintptr_t)((const uint8_t*)maps[cur_map].chfloor + (c & ~3u));
+        map_floor = (w >> (8u * (c & 3u))) & 0xFFu;
+      }
     }
     if (MIXED && !lng) {
       // ---- short blocks: up to eight consecutive ones as one pass (fused_short_pass) ---------------------------------------------
@@ -757,7 +762,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
 #ifndef VSYN_NO_MIXED_DMA
       if (MIXED && L) {
         if (!dma_ahead) {
-          issue_dma(pi.res_off + (uint64_t)c * ML);
+          issue_dma(pi.res_off + (uint64_t)c * ML, lane);
           dma_younger = 0;
         }
         if (dma_younger == 8u) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): the rows have landed; the 8 PCM stores behind them may still fly
@@ -985,7 +990,7 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
         dma_younger = 0xFFu;
         if (dma_ahead) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own reads of the image are done
-          issue_dma(pin.res_off + (uint64_t)c * ML);
+          issue_dma(pin.res_off + (uint64_t)c * ML, lane);
           dma_younger = 0;
         }
       }

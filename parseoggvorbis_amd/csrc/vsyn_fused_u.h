@@ -384,6 +384,11 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
         }
         const uint8_t* bs = A.binseg + (size_t)cur_floor * half1;
         const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2;
+        // (the bins' x as floats from a laundered lane number, so that the 16 NS values are not hoisted out of the block loop and
+        // spilled; 2 lane + an even literal is exact in f32)
+        uint32_t lane_x = lane;
+        asm volatile("" : "+v"(lane_x));
+        const float xf2 = (float)(2u * lane_x);
 #pragma unroll
         for (int u = 0; u < NS; ++u)
 #pragma unroll
@@ -392,7 +397,8 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
             const uint32_t two = nocurve ? 0u : (uint32_t) * (const uint16_t*)(bs + 2u * k);
             const u_f32x2 e0 = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * (two & 0xFFu));
             const u_f32x2 e1 = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * (two >> 8));
-            const uint32_t i0 = (uint32_t)__builtin_fmaf((float)(2u * k), e0.x, e0.y), i1 = (uint32_t)__builtin_fmaf((float)(2u * k + 1u), e1.x, e1.y);
+            const uint32_t i0 = (uint32_t)__builtin_fmaf(xf2 + (float)(1024 * u + 128 * t), e0.x, e0.y),
+                           i1 = (uint32_t)__builtin_fmaf(xf2 + (float)(1024 * u + 128 * t + 1), e1.x, e1.y);
             rb[u][t] = f2(rb[u][t].x * T.invdb[i0], rb[u][t].y * T.invdb[i1]);
             if (TAPC && !nocurve) {  // feature tap "floor1 floor" (hpp:585): the table indices are the rendered curve; packed like the residue
               ((uint32_t*)(A.curve + roff + (size_t)c * Mb))[k] = i0 | (i1 << 16);
@@ -691,6 +697,12 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
       }
       const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2;
       const bool nocurve = !((own_j >> c) & 1u);
+      // the bins' x as floats, rebuilt per packet from a laundered lane number: left to itself the compiler hoists all sixteen
+      // (float)(4 lane + 256 i + e) out of the pass loop, keeps them for the whole run and spills them (round 2: ~50 scratch
+      // reloads per pass, vector-memory operations queued behind the pass's look-ahead loads); 4 lane + (256 i + e) is exact in f32
+      uint32_t lane_x = lane;
+      asm volatile("" : "+v"(lane_x));
+      const float xf4 = (float)(4u * lane_x);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (256u * i >= M) break;
@@ -703,7 +715,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
           uint32_t cix[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const uint32_t ix = (uint32_t)__builtin_fmaf((float)(4u * lane + 256u * i + e), en[e].x, en[e].y);
+            const uint32_t ix = (uint32_t)__builtin_fmaf(xf4 + (float)(256 * i + e), en[e].x, en[e].y);
             fl[e] = T.invdb[ix];
             cix[e] = ix;
           }

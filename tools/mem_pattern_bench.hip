@@ -17,13 +17,16 @@
 
 constexpr uint32_t BLK = 1024;  // floats per block (one channel of one long packet)
 
-template <int WIDTH, bool LINEAR, bool WRITE, int NT = 0>
+template <int WIDTH, bool LINEAR, bool WRITE, int NT = 0, int ORDER = 0>
 __global__ void __launch_bounds__(512, 4) walk(const float* __restrict__ in, float* __restrict__ out, uint32_t streams, uint32_t runs, uint32_t R,
                                                 uint32_t ppk, uint64_t plane, int pace) {
   const uint32_t wave = blockIdx.x * 8 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t nwaves = streams * runs * 2;
   if (wave >= nwaves) return;
-  const uint32_t c = wave & 1u, r = (wave >> 1) % runs, s = (wave >> 1) / runs;
+  uint32_t c = wave & 1u, r = (wave >> 1) % runs, s = (wave >> 1) / runs;
+  if (ORDER == 1) { c = wave & 1u; s = (wave >> 1) % streams; r = (wave >> 1) / streams; }        // (r, s, c): a workgroup = 4 streams, same run index
+  else if (ORDER == 2) { r = wave % runs; s = (wave / runs) % streams; c = wave / (runs * streams); }  // (c, s, r)
+  else if (ORDER == 3) { r = wave % runs; c = (wave / runs) & 1u; s = wave / (2u * runs); }          // (s, c, r): a workgroup = 8 consecutive runs of one channel
   constexpr int V = WIDTH / 4;            // floats per lane per instruction
   constexpr int NI = BLK / (64 * V);      // instructions per block
   typedef float vec __attribute__((ext_vector_type(V)));
@@ -238,7 +241,7 @@ static void run_pair(const char* name, const float* in, float* out, uint32_t str
   printf("%-44s: %.3f ms  %.2f TB/s (read + write)\n", name, best, bytes / best / 1e9);
 }
 
-template <int WIDTH, bool LINEAR, bool WRITE, int NT = 0>
+template <int WIDTH, bool LINEAR, bool WRITE, int NT = 0, int ORDER = 0>
 static void run(const char* name, const float* in, float* out, uint32_t streams, uint32_t runs, uint32_t R, uint64_t plane, int pace) {
   const uint32_t ppk = runs * R, nwaves = streams * runs * 2;
   hipEvent_t e0, e1;
@@ -247,7 +250,7 @@ static void run(const char* name, const float* in, float* out, uint32_t streams,
   float best = 1e30f;
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipEventRecord(e0, 0));
-    walk<WIDTH, LINEAR, WRITE, NT><<<(nwaves + 7) / 8, 512>>>(in, out, streams, runs, R, ppk, plane, pace);
+    walk<WIDTH, LINEAR, WRITE, NT, ORDER><<<(nwaves + 7) / 8, 512>>>(in, out, streams, runs, R, ppk, plane, pace);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -292,6 +295,11 @@ int main(int argc, char** argv) {
   run_pol<5, 5>("policy: sc0 / sc0", in, out, streams, runs, R, plane);
   run_pol<0, 1>("policy: default / nt", in, out, streams, runs, R, plane);
   run_pol<1, 0>("policy: nt / default", in, out, streams, runs, R, plane);
+  // round 3: which (stream, run, channel) a wave gets — the kernel's order is (s, r, c): a workgroup = 4 consecutive runs x 2 channels
+  run<8, false, true, 3, 0>("order (s, r, c) [the kernel's], nt both", in, out, streams, runs, R, plane, 0);
+  run<8, false, true, 3, 1>("order (r, s, c), nt both", in, out, streams, runs, R, plane, 0);
+  run<8, false, true, 3, 2>("order (c, s, r), nt both", in, out, streams, runs, R, plane, 0);
+  run<8, false, true, 3, 3>("order (s, c, r), nt both", in, out, streams, runs, R, plane, 0);
   // other run lengths (same bytes): more, shorter runs = the resident waves cover a smaller address window at any time
   run<8, false, true, 3>("runs of 16 (x2 waves), nt both", in, out, streams, 2 * runs, R / 2, plane, 0);
   run<8, false, true, 3>("runs of 8 (x4 waves), nt both", in, out, streams, 4 * runs, R / 4, plane, 0);
