@@ -289,7 +289,11 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
       const uint32_t p = sg.first_packet + cur.q;
       const lds_u32* const pinf = pinf_base;
       const uint64_t roff = ((uint64_t)pinf[1] << 32) | pinf[0];
-      const uint32_t kap = ((lane & 7u) << 3) | (lane >> 3);
+      // (from a laundered lane number: everything derived from kappa — the carry-in addresses of the rare K_CARRY branch alone are 16 NS
+      // pointers — is otherwise hoisted out of the block loop and spilled)
+      uint32_t lane_k = lane;
+      asm volatile("" : "+v"(lane_k));
+      const uint32_t kap = ((lane_k & 7u) << 3) | (lane_k >> 3);
       // ---- loads ----
       float2 rb[NS][8];
       {
