@@ -1,7 +1,7 @@
 # tools/final_round.sh <tag> — the round-final measurement set on the GPU box (run from the repo root): PMC passes + kernel stats of the
 # default bench, bench lines of every workload, kernel stats over 200 steps and without overlap. Raw output under gpurun_out/<tag>*; copy
 # the summaries into profiles/.
-TAG=${1:-r02_z}
+TAG=${1:-r03_z}
 mkdir -p gpurun_out
 bash tools/profile_round.sh $TAG > gpurun_out/$TAG.log 2>&1
 echo "profile_round done"
@@ -18,11 +18,15 @@ B="timeout -k 10 400 python bench.py"
   $B --no-cpu-baseline --workload config3_vq --vq-books fixture ;
   $B --no-cpu-baseline --pcm-s16 ;
   $B --no-cpu-baseline --feature-taps ;
+  $B --no-cpu-baseline --steps 100 --feature-taps --blocksizes 128,1024 ;
+  VSYN_PREP_SERIAL=1 $B --steps 200 --warmup 10 --no-cpu-baseline ;
+  VSYN_PREP_SERIAL=1 $B --no-cpu-baseline --workload config4 ;
   $B --no-cpu-baseline --steps 100 --workload config3 --blocksizes 128,1024 ;
   $B --no-cpu-baseline --steps 100 --workload config4 --blocksizes 128,1024 ;
   $B --no-cpu-baseline --steps 100 --workload config3 --blocksizes 512,512 ;
   $B --no-cpu-baseline --steps 100 --workload config3 --blocksizes 1024,1024 ;
   $B --no-cpu-baseline --steps 50 --workload config3 --blocksizes 512,4096 --packets-per-stream 512 ;
+  $B --no-cpu-baseline --steps 50 --workload config4 --blocksizes 512,4096 --packets-per-stream 512 ;
   $B --no-cpu-baseline --steps 20 --workload config3 --blocksizes 1024,8192 --packets-per-stream 256 ;
   $B --no-cpu-baseline --steps 100 --streams 1 --packets-per-stream 65536 ;
   $B --no-cpu-baseline --steps 100 --streams 4096 --packets-per-stream 16 ;
