@@ -221,6 +221,25 @@ def test_bench_config5_line():
     assert j["config"]["packets_per_gpu"] == 96 * 94 and j["replicas_bit_identical"] and j["value"] > 0
 
 
+def test_bench_config5_full_size():
+    """BASELINE config 5 at its FULL per-GPU size — 10 640 replicas of the stereo fixture = 1 000 160 audio packets — through
+    bench.py exactly as the driver would run it on one GPU (one untimed pass, one timed): every replica must carry the reference
+    decoder's granule-derived frame count and the same checksum (bench.py asserts both), and the whole pass has to be a real-time
+    factor in the tens of thousands (it takes a quarter of a second on the box's 16 cores; the bound is generous)."""
+    import json
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "config5", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["config"]["packets_per_gpu"] == 10640 * 94 == 1000160 and j["replicas_bit_identical"]
+    assert j["frames_per_file"] == 91136          # the granule-derived total of the fixture (SURVEY 8b)
+    assert j["value"] > 2.5e5 and j["realtime_factor"] > 5000
+
+
 @pytest.mark.parametrize("vq", ["1", "0"])
 def test_synthetic_streams_pcm_matches_reference(vq, monkeypatch):
     """The 16 synthetic streams of tests/golden (oracle/make_synth_ogg.py: setups the real fixtures do not have, golden PCM from
