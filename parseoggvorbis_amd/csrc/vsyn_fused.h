@@ -1149,7 +1149,9 @@ __device__ __forceinline__ void fused_run(const FusedArgs& A, const FusedLdsImag
             }
           }
         }
-        vmem_drain();  // rare block: rejoin with nothing of its own pending (see vmem_drain)
+        // (stores only: nothing here loads a register, so the join needs no drain — one here waited for the block's PCM stores at every
+        // long -> short switch of a mixed run; the steady path reaches this block once per segment)
+        if (!MIXED) vmem_drain();
       }
     } else {
       // (short blocks of the mixed-block path are taken by fused_short_pass above)

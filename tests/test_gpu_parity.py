@@ -558,3 +558,44 @@ def test_chunked_layout_scan_twice_on_one_handle(streams, npk):
         gpu.reset()
         got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
         check(got, want)
+
+
+@pytest.mark.parametrize("run_len", [3, 130, 300])
+@pytest.mark.parametrize("C", [1, 2, 3])
+def test_preparation_kernel_geometries(run_len, C, monkeypatch):
+    """vsyn_prep_kernel (the dependency-free preparation of submits without VSYN_SUBMIT_INPUTS_READY) across its geometries: runs far
+    shorter than a workgroup's 256 rows (many runs per workgroup), runs longer than one pass (a run's packets spread over several
+    passes of a workgroup: class, scan carry and block size in front cross the pass boundary), 1-3 channels (rows per packet),
+    ragged segments, unused channels, page granules inside the streams. Against the oracle, and bit-identical to the two chained
+    pre-kernels (VSYN_SUBMIT_PRE_KERNELS) in emit_len, unwrapped posts and PCM."""
+    from parseoggvorbis_amd import sharding
+    monkeypatch.setenv("VSYN_RUN_LEN", str(run_len))
+    spec = fixture_like_spec(C)
+    if C > 2:
+        spec = SetupSpec(C, 256, 2048, spec.floors, [([(0, 1)], [0] * C), ([(0, 1)], [1] * C)], [(0, 0), (1, 1)])
+    lens = (701, 1, 333, 64)
+    bs = [synth_batch(spec, 1, k, "mixed", seed=100 + k, unused_frac=0.2, granule_last=True) for k in lens]
+    for x in bs:
+        pk = x["packets"]
+        abs_before, emit = sharding.stream_positions(spec, pk)
+        for q in range(10, len(pk) - 1, 11):
+            pk["granule"][q] = int(abs_before[q] + emit[q])
+    pk = np.concatenate([x["packets"] for x in bs])
+    ys = np.concatenate([x["ys"] for x in bs])
+    res = np.concatenate([x["residue"] for x in bs])
+    seg = np.zeros(len(bs), binding.SEGMENT_DTYPE)
+    first, roff = 0, 0
+    for i, x in enumerate(bs):
+        seg[i] = (i, first, len(x["packets"]), 1, roff)
+        first += len(x["packets"])
+        roff += x["residue"].size
+    plane = max(x["plane_stride"] for x in bs)
+    want = ob.OracleSynth(spec, len(bs)).submit_host(pk, seg, ys, res, plane)
+    gpu = binding.Synth(spec, max_streams=len(bs))
+    got = gpu.submit_host(pk, seg, ys, res, plane, want_taps="features")
+    check(got, want)
+    gpu.reset()
+    pre = gpu.submit_host(pk, seg, ys, res, plane, want_taps="features", flags=binding.VSYN_SUBMIT_PRE_KERNELS)
+    assert np.array_equal(pre["emit_len"], got["emit_len"])
+    assert np.array_equal(pre["taps"]["floor_final"], got["taps"]["floor_final"])
+    assert np.array_equal(bits(pre["pcm"]), bits(got["pcm"]))
