@@ -693,7 +693,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "packets_per_gpu": units, "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "latency" if args.workload == "config2" else "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
+            # what bounds the dominant kernel, from its counters: config 2 is a 6 MB batch (launch + one memory round trip);
+            # the residue VQ kernel spends 58 % of its wave cycles in s_waitcnt and is paced by ~2 900 instructions per packet on the CU's
+            # scalar unit and issue slots (profiles/r02_b_vq_kernel_pmc.json) — its fraction of the HBM peak is reported all the same
+            "roofline": {"bound": "latency" if args.workload == "config2" else ("instruction issue" if args.workload == "config3_vq" else "hbm"), "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_detail": traffic_detail,
                          "kernel": kern_name, "kernel_ms": round(kern_ms, 5), "launches": launches,

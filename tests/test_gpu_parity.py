@@ -435,8 +435,12 @@ def test_absolute_gate_at_unit_peak(pattern):
 
 
 def test_submit_flags_may_alternate_between_submits():
-    """vsyn_submit_device with and without VSYN_SUBMIT_INPUTS_READY in turn, on continuing streams, with work queued on the caller's
-    stream in front: the layout kernels of consecutive submits chain through the stream state whichever stream they run on."""
+    """vsyn_submit_device with a different preparation in every submit — the dependency-free preparation kernel on the caller's stream,
+    the chained pre-kernels on the internal stream (VSYN_SUBMIT_INPUTS_READY), the chained pre-kernels on the caller's stream
+    (VSYN_SUBMIT_PRE_KERNELS), the staged kernels — on continuing streams, with work queued on the caller's stream in front: consecutive
+    preparations chain through the tagged stream-state records whichever kernel writes them and whichever stream it runs on."""
+    FLAG_CYCLE = [0, binding.VSYN_SUBMIT_INPUTS_READY, binding.VSYN_SUBMIT_PRE_KERNELS, binding.VSYN_SUBMIT_INPUTS_READY,
+                  binding.VSYN_SUBMIT_STAGED, 0]
     import torch
     spec = fixture_like_spec(2)
     S, ppk, parts = 4, 24, 6
@@ -469,7 +473,7 @@ def test_submit_flags_may_alternate_between_submits():
             busy.add_(1.0)  # delayed work in front of the submit on the caller's stream
         gpu.submit_device(S * ppk, d["pk"].data_ptr(), S, d["seg"].data_ptr(), ppk, d["ys"].data_ptr(), d["res"].data_ptr(),
                           d["pcm"].data_ptr(), ppk * 1024 + 64, d["emit"].data_ptr(), None,
-                          binding.VSYN_SUBMIT_INPUTS_READY if k % 2 else 0, stream)
+                          FLAG_CYCLE[k % len(FLAG_CYCLE)], stream)
     fl, bad = gpu.sync_status(stream)
     assert fl == 0, (fl, bad)
     emit_want = want["emit_len"].reshape(S, parts, ppk)
