@@ -1,6 +1,6 @@
 // vsyn_fused_u.h — the size-generic fused synthesis kernel ("U"): every block-size pair 64..2048 (the reference runs every
 // size through the same code, hpp:1294-1298, mdct.cpp:353-373), any mix of short and long blocks, carry-ins, <= 2 channels with
-// at most one coupling step, <= 64 floor posts. One wavefront per (segment, run, channel) as in vsyn_fused.h; what is new:
+// at most one coupling step, <= 64 floor posts (this kernel: up to the spec's 65). One wavefront per (segment, run, channel) as in vsyn_fused.h; what is new:
 //
 //   * a wave always works on 512 complex points = 8 per lane. A block of n samples has Np = n/4 points, so a PASS takes
 //     J = 512/Np consecutive packets of the same size and mapping at once (n = 256: 8 packets; n = 1024: 2; n = 2048: 1; at most 8):
@@ -48,7 +48,7 @@ struct UBig {
 // per-wave LDS block (dynamic): exchange image | floor entries | packet info of the pass | next descriptors | hand-off flags | carry image
 #define U_XB_BYTES 4608u
 #define U_SEG_OFF U_XB_BYTES
-#define U_PINF_OFF (U_SEG_OFF + 512u)
+#define U_PINF_OFF (U_SEG_OFF + 528u)   /* 65 interval records: a 65-post floor's last post owns the flat stretch behind it */
 #define U_DNEXT_OFF (U_PINF_OFF + 256u)   /* descriptors of the next pass's candidates, 8 x 32 B, filled by LDS-DMA */
 #define U_FLAG_OFF (U_DNEXT_OFF + 256u)
 #define U_CBUF_OFF (U_FLAG_OFF + 16u)
@@ -122,9 +122,10 @@ struct UPass {
 };
 
 template <int ROLE, int UNS, bool TAPC>
-__device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, uint8_t* wmem, const uint8_t* pmem, const uint32_t wave_bytes, const uint32_t lane,
+__device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, uint8_t* wmem, const uint8_t* pmem, const uint32_t wave_bytes, const uint32_t lane_in,
                                       const uint32_t g, const vsyn_segment sg, const SegInfo si, const uint32_t qa, const uint32_t qb, const uint32_t C,
                                       const uint32_t c) {
+  uint32_t lane = lane_in;  // laundered at the top of every pass: nothing derived from it is hoisted out of the pass loop (and then spilled)
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
   float2* const xb = (float2*)wmem;
@@ -162,6 +163,9 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
   // floor in use (wave-uniform; reloaded when it changes)
   int cur_floor = -1;
   uint32_t cur_floor_M = 0, posts = 0, sidx = 0, xsl = 0;
+  // A 65-post floor (the spec's maximum) has one sorted post more than the wave has lanes: the last one — always header post 1, the
+  // largest x, always in use (hpp:533-534) — is kept wave-uniform: its header index and x here, its value read per packet.
+  uint32_t sidx64 = 0, xs64 = 0;
   uint32_t bsegw[4] = {0, 0, 0, 0};  // sorted-post interval of this lane's bins 4 lane + 256 i + {0..3}, one byte each
 
   // packet descriptors of the candidates of the pass to be formed next: lane j < 8 holds packet (start) + j
@@ -254,6 +258,10 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
     const bool in = lane < posts;
     sidx = in ? fc->sorted_idx[lane] : 0u;
     xsl = in ? fc->xs_sorted[lane] : 0u;
+    if (posts > 64u) {
+      sidx64 = __builtin_amdgcn_readfirstlane((uint32_t)fc->sorted_idx[64]);
+      xs64 = __builtin_amdgcn_readfirstlane((uint32_t)fc->xs_sorted[64]);
+    }
     cur_floor = (int)f;
     cur_floor_M = Mp;
     vmem_drain();
@@ -268,6 +276,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 #pragma unroll
     for (int k = 0; k < 8; ++k) PB[u][k] = 0.f;
   for (;;) {
+    asm volatile("" : "+v"(lane));
     // (Forming the NEXT pass early and requesting its residue a pass ahead was measured: 24 more live registers, no gain at the 8-12
     // waves per CU this kernel runs at — 0.221 vs 0.218 ms per 65 536 n = 1024 packets without spills, slower with them.)
     const UPass cur = form(qnext, 0u);
@@ -369,16 +378,25 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
           seg2[lane] = f2(0.f, ((used_b >> c) & 1u) ? 256.5f : 255.5f);
         } else {
           if (lane >= posts) v = 0;
+          const bool p65 = posts > 64u;
+          uint32_t packed64 = 0;
+          if (p65) {  // (rare: the extra load is exposed)
+            const uint32_t v64 = __builtin_amdgcn_readfirstlane((uint32_t)(A.fy + ((size_t)p * C + c) * ys_stride)[sidx64]) & 0x7FFFu;
+            packed64 = (xs64 << 16) | v64;
+            if (lane == 0) seg2[64] = f2(0.f, fminf((float)v64, 255.f));
+            floor_bad = v64 > 255u;
+          }
           const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
           const uint64_t below = mask & ((2ull << lane) - 1ull);
           const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
           const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
-          const bool has_hi = above != 0ull;
+          const bool has_hi = above != 0ull || p65;
           const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
           const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
           const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
-          const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
-          floor_bad = (v & 0x7FFFu) > 255u;
+          uint32_t phi = (uint32_t)__shfl((int)packed, (int)(above != 0ull ? hi : lo));
+          if (p65 && above == 0ull) phi = packed64;
+          floor_bad = floor_bad || (v & 0x7FFFu) > 255u;
           const float x0 = (float)(plo >> 16), y0 = fminf((float)(plo & 0xFFFFu), 255.f);
           const float x1 = (float)(phi >> 16), y1 = fminf((float)(phi & 0xFFFFu), 255.f);
           const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
@@ -679,15 +697,27 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
       } else {
         uint32_t v = (vcur[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
         if (lane >= posts) v = 0;
+        const bool p65 = posts > 64u;
+        uint32_t packed64 = 0;
+        if (p65) {  // (rare: the extra load is exposed)
+          const uint32_t v64 = __builtin_amdgcn_readfirstlane((uint32_t)(A.fy + ((size_t)(p0 + j) * C + c) * ys_stride)[sidx64]) & 0x7FFFu;
+          packed64 = (xs64 << 16) | v64;
+          if (lane == 0) seg2[64] = f2(0.f, fminf((float)v64, 255.f));
+          if (v64 > 255u) {
+            floor_bad = true;
+            floor_bad_pkt = p0 + j;
+          }
+        }
         const uint64_t mask = __ballot((v >> 15) != 0) | 1ull;
         const uint64_t below = mask & ((2ull << lane) - 1ull);
         const uint32_t lo = 63u - (uint32_t)__clzll((long long)below);
         const uint64_t above = lane < 63u ? (mask >> (lane + 1u)) : 0ull;
-        const bool has_hi = above != 0ull;
+        const bool has_hi = above != 0ull || p65;
         const uint32_t hi = lane + (uint32_t)__ffsll((long long)above);
         const uint32_t packed = (xsl << 16) | (v & 0x7FFFu);
         const uint32_t plo = (uint32_t)__shfl((int)packed, (int)lo);
-        const uint32_t phi = (uint32_t)__shfl((int)packed, (int)(has_hi ? hi : lo));
+        uint32_t phi = (uint32_t)__shfl((int)packed, (int)(above != 0ull ? hi : lo));
+        if (p65 && above == 0ull) phi = packed64;
         if ((v & 0x7FFFu) > 255u) {
           floor_bad = true;
           floor_bad_pkt = p0 + j;
@@ -1051,7 +1081,7 @@ static inline bool u_supported(const ConstHeader& H, const uint8_t* host_const) 
   if (H.bs[0] > 2048 || H.channels > U_MAX_CH) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
   for (uint32_t f = 0; f < H.num_floors; ++f)
-    if (fl[f].posts > 64) return false;
+    if (fl[f].posts > VSYN_MAX_POSTS) return false;  // (65 posts: the last sorted post is kept wave-uniform, see u_run)
   return true;
 }
 

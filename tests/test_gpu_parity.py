@@ -393,7 +393,9 @@ LIMITS = [
     (1, 33, 3, 2, False, "mixed", 3),  # mono, multiplier 3 on the long floor
     (2, 40, 4, 1, False, "mixed", 3),  # stereo WITHOUT a coupling step
     (2, 17, 2, 2, False, "long", 3),
-    (2, 65, 2, 4, True, "mixed", 0),   # 65 posts: beyond the fused kernel's one-ballot floor set-up -> staged kernels
+    (2, 65, 2, 4, True, "mixed", 2),   # 65 posts (the spec's maximum): one more than the tuned kernel's one-ballot set-up covers ->
+    (2, 65, 1, 1, False, "long", 2),   # every run on the size-generic kernel, which keeps the last sorted post wave-uniform
+    (1, 65, 3, 2, False, "mixed", 2),
 ]
 
 
@@ -407,6 +409,33 @@ def test_fused_path_limits(C, posts, ml, ms, coupled, pattern, paths):
     b = synth_batch(spec, 3, 37, pattern, seed=posts * 7 + ml, unused_frac=0.1, granule_last=True, ylo=20, yhi=70)
     gpu = binding.Synth(spec, max_streams=3)
     assert gpu.fused_paths == paths, (gpu.fused_paths, paths)
+    want = ob.OracleSynth(spec, 3).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
+    got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps="features")
+    check(got, want)
+    assert np.array_equal(got["taps"]["floor_final"], want["taps"]["floor_final"])
+    assert np.array_equal(got["taps"]["floor_curve"], want["taps"]["floor_curve"])
+    gpu.reset()
+    plain = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert np.array_equal(bits(plain["pcm"]), bits(got["pcm"]))
+    gpu.reset()
+    staged = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED)
+    check(staged, want)
+
+
+@pytest.mark.parametrize("bs0,bs1,posts_short,posts_long", [(256, 2048, 65, 65), (128, 1024, 65, 40), (512, 4096, 30, 65), (1024, 8192, 65, 65)])
+def test_65_post_floors_stay_fused(bs0, bs1, posts_short, posts_long):
+    """The spec's largest floor (65 posts, hpp:416-471) on short blocks, long blocks and blocks above 2048 samples (the register-set
+    path of the size-generic kernel): fused, posts / curve / PCM of the tap variant, the plain kernel and the staged kernels against the
+    oracle."""
+    rng = np.random.default_rng(bs1 + posts_short)
+
+    def xs(n2, posts):
+        return [0, n2] + [int(v) for v in rng.choice(np.arange(1, n2), posts - 2, replace=False)]
+    spec = SetupSpec(2, bs0, bs1, [(2, xs(bs0 // 2, posts_short)), (1, xs(bs1 // 2, posts_long))],
+                     [([(0, 1)], [0, 0]), ([(0, 1)], [1, 1])], [(0, 0), (1, 1)])
+    b = synth_batch(spec, 3, 29, "mixed", seed=posts_long + bs0, unused_frac=0.1, granule_last=True, ylo=20, yhi=70)
+    gpu = binding.Synth(spec, max_streams=3)
+    assert gpu.fused_paths & 2, gpu.fused_paths
     want = ob.OracleSynth(spec, 3).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
     got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps="features")
     check(got, want)
