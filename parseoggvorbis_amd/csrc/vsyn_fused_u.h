@@ -1076,19 +1076,26 @@ struct UTables {
   uint32_t wave_bytes = 0, table_bytes = 0, waves_per_block = 0, waves_per_cu = 0, role_mode = 0, ns = 1;
 };
 
+static inline uint32_t u_role_mode(const ConstHeader& H, const uint8_t* host_const);
 static inline bool u_supported(const ConstHeader& H, const uint8_t* host_const) {
-  // blocksize1 up to 8192 (register sets, UBig); blocksize0 must fit the packed passes
-  if (H.bs[0] > 2048 || H.channels > U_MAX_CH) return false;
+  // blocksize1 up to 8192 (register sets, UBig); blocksize0 must fit the packed passes. The channel waves of a run share one workgroup
+  // (12 waves) when any mapping couples channels; a setup without coupling steps has no such tie: any channel count.
+  if (H.bs[0] > 2048 || (H.channels > U_MAX_CH && u_role_mode(H, host_const) != 0u)) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
   for (uint32_t f = 0; f < H.num_floors; ++f)
     if (fl[f].posts > VSYN_MAX_POSTS) return false;  // (65 posts: the last sorted post is kept wave-uniform, see u_run)
   return true;
 }
 
-// 0 / 1 / 2: stereo or mono with the same (at most one) coupling step in every mapping — the pairwise row swap; 3: the general replay
+// 0 / 1 / 2: stereo or mono with the same (at most one) coupling step in every mapping — the pairwise row swap (0: no coupling at all,
+// any channel count); 3: the general replay
 static inline uint32_t u_role_mode(const ConstHeader& H, const uint8_t* host_const) {
   const MapConst* mp = (const MapConst*)(host_const + H.off_map);
-  if (H.channels > 2) return 3;
+  if (H.channels > 2) {  // no coupling step in any mapping in use: every channel wave on its own (role 0), whatever the channel count
+    bool any = false;
+    for (uint32_t k = 0; k < H.num_modes; ++k) any = any || mp[H.mode_mapping[k]].ncoup != 0;
+    return any ? 3u : 0u;
+  }
   int want = -2;
   for (uint32_t k = 0; k < H.num_modes; ++k) {
     const MapConst& m = mp[H.mode_mapping[k]];

@@ -525,6 +525,9 @@ MULTI = [
     (5, 512, 512, []),
     (4, 64, 256, [(0, 1), (2, 3), (0, 2), (1, 3)]),
     (2, 256, 1024, [(1, 0), (0, 1)]),            # stereo with a two-step chain: not the pairwise swap
+    (16, 128, 1024, []),                         # more channels than one workgroup has waves: fused while no mapping couples any
+    (13, 256, 2048, []),
+    (3, 512, 4096, []),                          # uncoupled channels on the register-set path
 ]
 
 
@@ -543,6 +546,18 @@ def test_multichannel_and_chained_couplings_stay_fused(C, bs0, bs1, coup):
     gpu.reset()
     staged = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED)
     check(staged, want)
+
+
+def test_more_than_12_coupled_channels_take_the_staged_kernels():
+    """The channel waves of a coupled run share one workgroup (12 waves): 13+ channels WITH a coupling step are the one channel layout
+    left to the staged kernels — asserted, and still equal to the oracle."""
+    base = fixture_like_spec(1, 128, 1024)
+    spec = SetupSpec(14, 128, 1024, base.floors, [([(0, 13)], [0] * 14), ([(0, 13)], [1] * 14)], [(0, 0), (1, 1)])
+    b = synth_batch(spec, 2, 21, "mixed", seed=14, unused_frac=0.2, granule_last=True)
+    gpu = binding.Synth(spec, max_streams=2)
+    assert gpu.fused_paths == 0, gpu.fused_paths
+    want = ob.OracleSynth(spec, 2).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    check(gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"]), want)
 
 
 MIXED_MAPPINGS = [
