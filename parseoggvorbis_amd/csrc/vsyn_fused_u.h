@@ -1080,7 +1080,8 @@ static inline uint32_t u_role_mode(const ConstHeader& H, const uint8_t* host_con
 static inline bool u_supported(const ConstHeader& H, const uint8_t* host_const) {
   // blocksize1 up to 8192 (register sets, UBig); blocksize0 must fit the packed passes. The channel waves of a run share one workgroup
   // (12 waves) when any mapping couples channels; a setup without coupling steps has no such tie: any channel count.
-  if (H.bs[0] > 2048 || (H.channels > U_MAX_CH && u_role_mode(H, host_const) != 0u)) return false;
+  // (a blocksize0 above 2048 only when it equals blocksize1: every block then takes the register-set path, whatever its mode says)
+  if ((H.bs[0] > 2048 && H.bs[0] != H.bs[1]) || (H.channels > U_MAX_CH && u_role_mode(H, host_const) != 0u)) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);
   for (uint32_t f = 0; f < H.num_floors; ++f)
     if (fl[f].posts > VSYN_MAX_POSTS) return false;  // (65 posts: the last sorted post is kept wave-uniform, see u_run)
@@ -1179,7 +1180,7 @@ static inline hipError_t u_tables_create(const ConstHeader& H, const uint8_t* ho
   const uint32_t big_bytes = ns == 2 ? (uint32_t)sizeof(UBig<2>) : (ns == 4 ? (uint32_t)sizeof(UBig<4>) : 0u);
   std::vector<uint8_t> blob(img_bytes + big_bytes, 0);
   ULdsImage& im = *(ULdsImage*)blob.data();
-  u_fill_size(H, host_const, 0, im.sz[0]);
+  if (H.bs[0] <= 2048) u_fill_size(H, host_const, 0, im.sz[0]);  // (the packed passes' tables; unused when every block is above 2048)
   if (ns == 1) u_fill_size(H, host_const, 1, im.sz[1]);
   else if (ns == 2) u_fill_big<2>(H, host_const, im.sz[1], *(UBig<2>*)(blob.data() + img_bytes));
   else u_fill_big<4>(H, host_const, im.sz[1], *(UBig<4>*)(blob.data() + img_bytes));

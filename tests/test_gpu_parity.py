@@ -95,6 +95,8 @@ SHAPES = [  # (channels, bs0, bs1, pattern, streams, packets)
     (2, 512, 4096, "mixed", 2, 35),    # blocks above 2048: register sets (UBig)
     (1, 256, 4096, "mixed", 2, 30),
     (2, 4096, 4096, "long", 2, 10),
+    (2, 4096, 4096, "mixed", 2, 14),   # blocksize0 == blocksize1 above 2048: every block on the register-set path, whatever its mode
+    (1, 8192, 8192, "mixed", 2, 9),
     (2, 1024, 8192, "mixed", 2, 28),
     (1, 64, 8192, "mixed", 1, 40),
     (2, 256, 2048, "mixed", 2, 2300),  # segments of several thousand packets: the layout kernel's bursts
@@ -546,6 +548,26 @@ def test_multichannel_and_chained_couplings_stay_fused(C, bs0, bs1, coup):
     gpu.reset()
     staged = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED)
     check(staged, want)
+
+
+@pytest.mark.parametrize("C,bs,pattern", [(2, 4096, "mixed"), (2, 8192, "mixed"), (1, 8192, "short"), (3, 4096, "long")])
+def test_equal_block_sizes_above_2048_stay_fused(C, bs, pattern):
+    """blocksize0 == blocksize1 of 4096 / 8192 (hpp:1294-1298: one code path for every size): blocks of both modes take the
+    size-generic kernel's register-set path. Run class asserted; posts, curve and PCM against the oracle; staged kernels beside it."""
+    spec = fixture_like_spec(C, bs, bs)
+    b = synth_batch(spec, 2, 11, pattern, seed=bs + C, unused_frac=0.15, granule_last=True)
+    gpu = binding.Synth(spec, max_streams=2)
+    assert gpu.fused_paths & 2, gpu.fused_paths
+    want = ob.OracleSynth(spec, 2).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps=True)
+    got = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], want_taps="features")
+    check(got, want)
+    assert np.array_equal(got["taps"]["floor_final"], want["taps"]["floor_final"])
+    assert np.array_equal(got["taps"]["floor_curve"], want["taps"]["floor_curve"])
+    gpu.reset()
+    plain = gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
+    assert np.array_equal(bits(plain["pcm"]), bits(got["pcm"]))
+    gpu.reset()
+    check(gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED), want)
 
 
 def test_more_than_12_coupled_channels_take_the_staged_kernels():
