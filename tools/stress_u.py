@@ -17,19 +17,22 @@ SIZES = [64, 128, 256, 512, 1024, 2048, 4096, 8192]
 worst = 0.0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    C = int(rng.choice([1, 2, 2, 3, 4, 5, 6]))
+    C = int(rng.choice([1, 2, 2, 3, 4, 5, 6, 2, 13, 16]))
     i1 = int(rng.integers(0, len(SIZES)))
     i0 = int(rng.integers(0, min(i1, 5) + 1))
+    if rng.random() < 0.15:
+        i0 = i1  # equal sizes, 4096 / 8192 included: every block on the register-set path
     bs0, bs1 = SIZES[i0], SIZES[i1]
 
     def xs(n2, posts):
         posts = min(posts, n2 + 1)
         inner = rng.choice(np.arange(1, n2), posts - 2, replace=False) if posts > 2 else np.zeros(0, np.int64)
         return [0, n2] + [int(v) for v in inner]
-    floors = [(int(rng.integers(1, 5)), xs(bs0 // 2, int(rng.integers(2, 30)))), (int(rng.integers(1, 5)), xs(bs1 // 2, int(rng.integers(2, 65))))]
+    floors = [(int(rng.integers(1, 5)), xs(bs0 // 2, int(rng.choice([65, 64, 33]) if rng.random() < 0.1 else rng.integers(2, 30)))),
+              (int(rng.integers(1, 5)), xs(bs1 // 2, 65 if rng.random() < 0.15 else int(rng.integers(2, 65))))]
     def coup():
         out = []
-        for _ in range(int(rng.integers(0, 4)) if C > 1 else 0):
+        for _ in range(int(rng.integers(0, 4)) if 1 < C <= 12 else 0):  # (13+ channels: uncoupled, the layout that stays fused)
             m, a = rng.choice(C, 2, replace=False)
             out.append((int(m), int(a)))
         return out
@@ -37,8 +40,6 @@ for seed in range(first, first + count):
     npk = int(rng.integers(3, 60 if bs1 <= 2048 else 24))
     streams = int(rng.integers(1, 4))
     flags = (rng.random(npk) < 0.5).astype(np.uint8)
-    if bs0 == bs1:
-        flags[:] = 1
     b = synth_batch(spec, streams, npk, flags, seed=seed, unused_frac=0.2, granule_last=bool(rng.integers(0, 2)), ylo=20, yhi=70)
     if rng.random() < 0.5:
         os.environ["VSYN_RUN_LEN"] = str(int(rng.integers(2, 12)))
