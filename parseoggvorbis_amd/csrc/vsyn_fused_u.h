@@ -53,6 +53,7 @@ struct UBig {
 #define U_FLAG_OFF (U_DNEXT_OFF + 256u)
 #define U_CBUF_OFF (U_FLAG_OFF + 16u)
 #define U_MAX_J 8u
+#define U_TAB_STRIDE 65u  /* line records per packet table of a packed pass (a 65-post floor's last post owns the stretch behind it) */
 #ifndef U_MAX_THREADS
 #define U_MAX_THREADS 768  // 12 waves per workgroup, one workgroup per CU: 168 VGPRs per wave
 #endif
@@ -130,7 +131,6 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
   const ConstHeader* H = hdr_of(cb);
   float2* const xb = (float2*)wmem;
   const float2* const pxb = (const float2*)pmem;
-  float* const stage = (float*)wmem;  // floor factors of the pass in bin order (the exchange image is idle between hand-off and FFT)
   float2* const seg2 = (float2*)(wmem + U_SEG_OFF);
   lds_u32* const pinf_base = (lds_u32*)(wmem + U_PINF_OFF);  // packet table of the pass in work
   lds_u32* const my_flags = (lds_u32*)(wmem + U_FLAG_OFF);
@@ -166,7 +166,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
   // A 65-post floor (the spec's maximum) has one sorted post more than the wave has lanes: the last one — always header post 1, the
   // largest x, always in use (hpp:533-534) — is kept wave-uniform: its header index and x here, its value read per packet.
   uint32_t sidx64 = 0, xs64 = 0;
-  uint32_t bsegw[4] = {0, 0, 0, 0};  // sorted-post interval of this lane's bins 4 lane + 256 i + {0..3}, one byte each
+  uint32_t bsege[4] = {0, 0, 0, 0};  // sorted-post intervals of the two bins of this lane's element t (point k = (64 t + lane) mod Np: bins 2k, 2k + 1), 16 bits per t
 
   // packet descriptors of the candidates of the pass to be formed next: lane j < 8 holds packet (start) + j
   // They come by LDS-DMA (one 4-byte piece per lane: 256 contiguous bytes = descriptors qq .. qq+7; the workspace has slack behind
@@ -254,7 +254,10 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
     posts = __builtin_amdgcn_readfirstlane(fc->posts);
     const uint8_t* bs = A.binseg + (size_t)f * half1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bsegw[i] = (4u * lane + 256u * i < Mp) ? *(const uint32_t*)(bs + 4u * lane + 256u * i) : 0u;
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t k0 = (64u * (2u * i) + lane) & (Mp / 2u - 1u), k1 = (64u * (2u * i + 1u) + lane) & (Mp / 2u - 1u);
+      bsege[i] = (uint32_t) * (const uint16_t*)(bs + 2u * k0) | ((uint32_t) * (const uint16_t*)(bs + 2u * k1) << 16);
+    }
     const bool in = lane < posts;
     sidx = in ? fc->sorted_idx[lane] : 0u;
     xsl = in ? fc->xs_sorted[lane] : 0u;
@@ -685,15 +688,24 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
 
     if (ROLE == 1 || ROLE == 2) pair_wait(&partner_flags[1], ep);  // the partner has read this wave's image: it may be reused (floor factors, FFT)
 
-    // ---- floor curve, packet by packet, in bin order (hpp:563-589) -----------------------------------------------------------------
+    // ---- floor curve + product (hpp:563-589, 1243-1255) --------------------------------------------------------------------------------
+    // One table of per-interval line records per packet of the pass (65 records each, side by side in the exchange image, which is
+    // idle between the hand-off and the FFT), then every ELEMENT looks its two bins up in the table of its own packet: no detour of
+    // the factors through LDS in bin order (round 2's form: a 16-byte write and an 8-byte read per four / two bins, ~100 more vector
+    // instructions per pass).
     bool floor_bad = false;
     uint32_t floor_bad_pkt = 0;
+    uint32_t nocurve_mask = 0;
+    float2* const tabs = xb;
 #pragma unroll
     for (uint32_t j = 0; j < U_MAX_J; ++j) {
       if (j >= Jp) break;
+      float2* const tab = tabs + U_TAB_STRIDE * j;
       const uint32_t own_j = pinf[8u * j + 5u], used_j = pinf[8u * j + 4u];
       if (!((own_j >> c) & 1u)) {
-        seg2[lane] = f2(0.f, ((used_j >> c) & 1u) ? 256.5f : 255.5f);  // x1.0 resp. x0.0 (hpp:1159,1176-1179), as in vsyn_fused.h
+        nocurve_mask |= 1u << j;
+        tab[lane] = f2(0.f, ((used_j >> c) & 1u) ? 256.5f : 255.5f);  // x1.0 resp. x0.0 (hpp:1159,1176-1179), as in vsyn_fused.h
+        if (lane == 0) tab[64] = f2(0.f, ((used_j >> c) & 1u) ? 256.5f : 255.5f);
       } else {
         uint32_t v = (vcur[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
         if (lane >= posts) v = 0;
@@ -702,7 +714,7 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
         if (p65) {  // (rare: the extra load is exposed)
           const uint32_t v64 = __builtin_amdgcn_readfirstlane((uint32_t)(A.fy + ((size_t)(p0 + j) * C + c) * ys_stride)[sidx64]) & 0x7FFFu;
           packed64 = (xs64 << 16) | v64;
-          if (lane == 0) seg2[64] = f2(0.f, fminf((float)v64, 255.f));
+          if (lane == 0) tab[64] = f2(0.f, fminf((float)v64, 255.f));
           if (v64 > 255u) {
             floor_bad = true;
             floor_bad_pkt = p0 + j;
@@ -727,46 +739,31 @@ __device__ __forceinline__ void u_run(const FusedArgs& A, const ULdsImage& T, ui
         const float inv = has_hi ? __builtin_amdgcn_rcpf(x1 - x0) : 0.f;
         const float ady = fabsf(y1 - y0);
         const float a = ady * inv, b = __builtin_fmaf(-ady, x0, 0.5f) * inv;
-        seg2[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);  // index = floor(x a + b), see vsyn_fused.h
-      }
-      const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2;
-      const bool nocurve = !((own_j >> c) & 1u);
-      // the bins' x as floats, rebuilt per packet from a laundered lane number: left to itself the compiler hoists all sixteen
-      // (float)(4 lane + 256 i + e) out of the pass loop, keeps them for the whole run and spills them (round 2: ~50 scratch
-      // reloads per pass, vector-memory operations queued behind the pass's look-ahead loads); 4 lane + (256 i + e) is exact in f32
-      uint32_t lane_x = lane;
-      asm volatile("" : "+v"(lane_x));
-      const float xf4 = (float)(4u * lane_x);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (256u * i >= M) break;
-        if (4u * lane + 256u * i < M) {
-          const uint32_t w = nocurve ? 0u : bsegw[i];
-          u_f32x2 en[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) en[e] = *(const u_lds_f32x2*)(uintptr_t)(seg_base + 8u * ((w >> (8 * e)) & 0xFFu));
-          u_f32x4 fl;
-          uint32_t cix[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t ix = (uint32_t)__builtin_fmaf(xf4 + (float)(256 * i + e), en[e].x, en[e].y);
-            fl[e] = T.invdb[ix];
-            cix[e] = ix;
-          }
-          *(u_lds_f32x4*)(lds_f32*)(stage + j * M + 4u * lane + 256u * i) = fl;
-          if (TAPC && !nocurve) {  // feature tap "floor1 floor" (hpp:585): four consecutive bins of packet j, 8 bytes per lane
-            const uint64_t roff = ((uint64_t)pinf[8u * j + 1u] << 32) | pinf[8u * j];
-            *(uint2*)(A.curve + roff + (size_t)c * M + 4u * lane + 256u * i) = make_uint2(cix[0] | (cix[1] << 16), cix[2] | (cix[3] << 16));
-          }
-        }
+        tab[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);  // index = floor(x a + b), see vsyn_fused.h
       }
     }
-    // floor product in element order (hpp:1243-1255)
+    {
+      // element (t, lane) = point k of packet jt: bins 2k, 2k + 1. Their x as floats from a laundered lane number (left to itself the
+      // compiler hoists the per-register values out of the pass loop and spills them); 2 (lane & kmask) + an even literal is exact.
+      uint32_t lane_x = lane;
+      asm volatile("" : "+v"(lane_x));
+      const float xfl = (float)(2u * (lane_x & kmask));
+      const uint32_t tabs_base = (uint32_t)(uintptr_t)(lds_u32*)tabs;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const uint32_t e = 64u * t + lane, jt = min(e >> LG, Jp - 1u), k = e & kmask;
-      const u_f32x2 f = *(const u_lds_f32x2*)(lds_f32*)(stage + jt * M + 2u * k);
-      r[t] = f2(r[t].x * f.x, r[t].y * f.y);
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t e = 64u * t + lane, je = e >> LG, jt = min(je, Jp - 1u);
+        const uint32_t two = (bsege[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;  // interval of bin 2k | of bin 2k + 1 << 8
+        const uint32_t tb = tabs_base + (U_TAB_STRIDE * 8u) * jt;
+        const u_f32x2 e0 = *(const u_lds_f32x2*)(uintptr_t)(tb + 8u * (two & 0xFFu));
+        const u_f32x2 e1 = *(const u_lds_f32x2*)(uintptr_t)(tb + 8u * (two >> 8));
+        const float xk = xfl + (float)(2u * ((64u * (uint32_t)t) & kmask));
+        const uint32_t i0 = (uint32_t)__builtin_fmaf(xk, e0.x, e0.y), i1 = (uint32_t)__builtin_fmaf(xk + 1.f, e1.x, e1.y);
+        r[t] = f2(r[t].x * T.invdb[i0], r[t].y * T.invdb[i1]);
+        if (TAPC && je < Jp && !((nocurve_mask >> jt) & 1u)) {  // feature tap "floor1 floor" (hpp:585): packed like the residue
+          const uint64_t roff = ((uint64_t)pinf[8u * jt + 1u] << 32) | pinf[8u * jt];
+          ((uint32_t*)(A.curve + roff + (size_t)c * M))[e & kmask] = i0 | (i1 << 16);
+        }
+      }
     }
 
     // ---- IMDCT: mirror element, pre-rotation, FFT-Np x J, post-rotation (mdct.cpp:433-527 by the DCT-IV route) ---------------------
