@@ -333,7 +333,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
   for (uint32_t t = 0; t < 8; ++t) {
     const uint32_t tc = min(t, Jp - 1u);
     const uint64_t off = ((uint64_t)__builtin_amdgcn_readlane(da[1], tc) << 32) | (uint32_t)__builtin_amdgcn_readlane(da[0], tc);
-    raw[t] = ((const float2*)(A.residue + off + (size_t)c * MS))[lane];
+    raw[t] = (VSYN_KNOCKOUT & 256) ? f2(0.001f * (float)lane, 0.002f) : ((const float2*)(A.residue + off + (size_t)c * MS))[lane];
     vrow[t] = (A.fy + ((size_t)(p0 + tc) * C + c) * ys_stride)[sidx];
   }
 #pragma unroll
@@ -341,7 +341,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
     if (t >= Jp) raw[t] = f2(0.f, 0.f);
   // ---- inverse coupling through the partner's image ----------------------------------------------------------------------------------
   float2 r[8];
-  if (ROLE != 0) {
+  if (ROLE != 0 && !(VSYN_KNOCKOUT & 512)) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) xb[t * 64 + lane] = raw[t];
     STAMP(10);  // short pass: rows arrived, written to the exchange image
@@ -361,13 +361,13 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
   // Two phases over the pass's packets, so that the eight set-ups (ballot, two bpermutes, table write) and then the eight look-up
   // chains (entry, inverse-dB value) overlap each other instead of running back to back: the eight tables live in the exchange
   // image, which is idle between the hand-off and the FFT (one table per packet, 512 bytes each).
-  if (ROLE != 0) pair_wait(&partner_flags[1], epoch);  // the partner has read this wave's image: it may be reused
+  if (ROLE != 0 && !(VSYN_KNOCKOUT & 512)) pair_wait(&partner_flags[1], epoch);  // the partner has read this wave's image: it may be reused
   bool floor_bad = false;
   uint32_t floor_bad_pkt = 0;
   uint32_t nocurve_mask = 0;
 #pragma unroll
   for (uint32_t t = 0; t < 8; ++t) {
-    if (t >= Jp) break;
+    if (t >= Jp || (VSYN_KNOCKOUT & 64)) break;
     float2* const tab = xb + 64u * t;
     const uint32_t own_t = __builtin_amdgcn_readlane(db[1], t), used_t = __builtin_amdgcn_readlane(db[0], t);
     if (!((own_t >> c) & 1u)) {
@@ -397,7 +397,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
       tab[lane] = y1 >= y0 ? f2(a, b + y0) : f2(-a, (y0 + 1.f) - b);
     }
   }
-  {
+  if (!(VSYN_KNOCKOUT & 64)) {
     typedef float lds_vf2 __attribute__((ext_vector_type(2)));
     const uint32_t seg_base = (uint32_t)(uintptr_t)(lds_u32*)seg2, xb_base = (uint32_t)(uintptr_t)(lds_u32*)xb;
     // bseg0 holds the entry addresses inside the wave's own floor table: rebase them onto table t of the image
@@ -430,7 +430,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
 #pragma unroll
     for (int t = 0; t < 8; ++t) z[t] = cmulf(f2(r[t].x, __shfl(r[t].y, 63 - (int)lane)), pre);  // X[127 - 2k] lives in lane 63-k
   }
-  {
+  if (!(VSYN_KNOCKOUT & 128)) {
     const uint32_t cl = lane & 7u, hi = lane >> 3;
 #pragma unroll
     for (int t = 0; t < 8; ++t) xb[t * 72 + lane] = z[t];
@@ -516,7 +516,7 @@ __device__ __forceinline__ uint32_t fused_short_pass(const FusedArgs& A, const F
     n_s[j] = __shfl(ol_s, mirror);
     n_m[j] = __shfl(ol_m, mirror);
   }
-  {
+  if (!(VSYN_KNOCKOUT & 32) || oh_s[0] == 1234.567f) {
     const bool whole = emit == MS + shift && (((uintptr_t)out & 7u) == 0);
     if (__all(whole || !valid_o)) {
       if (valid_o) {
