@@ -31,7 +31,8 @@
 #define FUSED_XSLOTS 576  // float2 slots of the per-wave exchange image: 8 rows x 72 (>= 8 x 65)
 // Diagnostic builds only (tools/ab_variants.sh): -DVSYN_KNOCKOUT=<bits> removes one phase of the long-block loop so that its
 // marginal cost can be timed (the results are then wrong by construction): 1 channel hand-off + coupling, 2 floor product,
-// 4 FFT, 8 PCM stores, 16 floor set-up, 32 window/overlap arithmetic.
+// 4 FFT, 8 PCM stores, 16 floor set-up; of the packed short pass: 32 PCM stores, 64 floor (tables, look-ups, product), 128 FFT-64,
+// 256 residue loads, 512 coupling hand-off.
 #ifndef VSYN_KNOCKOUT
 #define VSYN_KNOCKOUT 0
 #endif
