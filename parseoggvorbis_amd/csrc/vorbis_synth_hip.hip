@@ -684,7 +684,12 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   //   the preparation kernel on the internal stream (VSYN_PREP_OVERLAP=1): 0.266 ms, its 256-thread / 121-VGPR workgroups cost the
   //   exact-fit synthesis grid more than the two small kernels do. (b) is what the host-buffer entry points get: 20 instead of ~35 us.
   static const bool env_no_prep_kernel = getenv("VSYN_NO_PREP_KERNEL") && atoi(getenv("VSYN_NO_PREP_KERNEL"));
-  static const bool env_prep_serial = getenv("VSYN_PREP_SERIAL") && atoi(getenv("VSYN_PREP_SERIAL"));
+  // VSYN_PREP_SERIAL: 1 = (b) for VSYN_SUBMIT_INPUTS_READY submits too, 0 = never; unset = where it measured faster: setups whose runs
+  // all go to the size-generic kernel (its 16-wave workgroups fill a CU's registers exactly: hidden pre-kernels have to wait for its
+  // tail, and the single-queue form is 2-4 % faster per step on every such workload measured — 128/1024, 256/512, 512/512, 1024/1024,
+  // long and mixed; profiles/r03_experiments/generic_kernel_16_waves.txt).
+  static const int env_prep_serial_mode = getenv("VSYN_PREP_SERIAL") ? (atoi(getenv("VSYN_PREP_SERIAL")) ? 1 : 0) : -1;
+  const bool env_prep_serial = env_prep_serial_mode == 1 || (env_prep_serial_mode < 0 && use_u && !(fmask & 1u) && h->utab.ns == 1);
   static const bool env_prep_overlap = getenv("VSYN_PREP_OVERLAP") && atoi(getenv("VSYN_PREP_OVERLAP"));
   const bool prep_ok = !force_staged && (fmask & 2u) && !d_vq && max_seg_packets <= PREP_MAX_SEG_PACKETS && !(flags & VSYN_SUBMIT_PRE_KERNELS) && !env_no_prep_kernel;
   const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged && !(env_prep_serial && prep_ok);
