@@ -271,6 +271,10 @@ static int build_const(const vsyn_setup* su, uint32_t max_streams, vsyn_handle* 
       }
       fc.ngroups = ng;  // <= 63 (one group per post at worst)
     }
+    // floors of <= 32 posts take the register chain of vsyn_prep.h, which reads the flag bits a coded post touches — itself and its two
+    // neighbours — from the 4th dword of pk[] (sched[] above keeps the post's own index there)
+    if (sf.num_posts <= 32)
+      for (uint32_t i = 2; i < sf.num_posts; ++i) fc.pk[i].idx = (1u << fc.lo[i]) | (1u << fc.hi[i]) | (1u << i);
   }
   H.ys_stride = (maxp + 3u) & ~3u;
   h->prep_lds_bytes = maxp > 32 ? H.ys_stride * PREP_THREADS * (uint32_t)sizeof(uint32_t) : 16u;  // (floors of <= 32 posts stay in registers)

@@ -30,7 +30,7 @@ struct FloorConst {               // one floor-1 configuration (VorbisFloor1, hp
     uint16_t lo, hi;                       // neighbour header indices
     uint16_t dxi, adx;                     // xs[i] - xs[lo], xs[hi] - xs[lo]
     float inv_adx;                         // 1 / adx
-    uint32_t idx;                          // (sched[] only) header index of the post
+    uint32_t idx;                          // sched[]: header index of the post; pk[] of a floor of <= 32 posts: (1 << lo) | (1 << hi) | (1 << i)
   } pk[VSYN_MAX_POSTS + 1];
   // Step 1 as a schedule of GROUPS of up to four mutually independent posts (same depth in the neighbour tree: a post depends on
   // its two neighbours only): a lane that unwraps a row works on four posts at once instead of one (vsyn_prep.h). Unused entries of

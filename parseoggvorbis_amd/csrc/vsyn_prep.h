@@ -115,49 +115,72 @@ __device__ __forceinline__ void prep_unwrap_rows(const PrepCtx& A, const bool ac
       // 2x that per post (an access to the array is an s_set_gpr_idx mode switch; four chains side by side do not make up for it).
       uint32_t fr[32];
       const uint2* in8 = (const uint2*)(A.ys + gid * stride);
+      uint2 win[8];
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
-        uint2 w = make_uint2(0u, 0u);
-        if (j * 4 < posts) w = in8[j];
-        fr[4 * j + 0] = w.x & 0xFFFFu;
-        fr[4 * j + 1] = w.x >> 16;
-        fr[4 * j + 2] = w.y & 0xFFFFu;
-        fr[4 * j + 3] = w.y >> 16;
+        win[j] = make_uint2(0u, 0u);
+        if (j * 4 < posts) win[j] = in8[j];
       }
       uint32_t flags = 3;
       bool bad = false;
-      auto step = [&](const uint32_t i, const uint32_t kx, const uint32_t ky, const uint32_t kz) {
-        const uint32_t lo = kx & 0xFFFFu, hi = kx >> 16;
-        const uint32_t val = fr[i], ylo = fr[lo], yhi = fr[hi];
-        const uint32_t dxi = ky & 0xFFFFu, adx = ky >> 16;
-        const bool up = yhi >= ylo;
-        const uint32_t ady = up ? yhi - ylo : ylo - yhi;
-        const uint32_t prod = ady * dxi;
-        uint32_t off = (uint32_t)(((float)prod + 0.5f) * __uint_as_float(kz));
-        const bool big_in = prod >= (1u << 21) || ady >= 65536u;  // beyond the float path's exact range (vsyn_staged.h, predict_post)
-        if (__any(big_in)) off = big_in ? prod / adx : off;
-        const uint32_t predicted = up ? ylo + off : ylo - off;
-        const bool ok = predicted <= range;  // hpp:536
-        const uint32_t pr = ok ? predicted : 0u;
-        const uint32_t high_room = range - pr, low_room = pr;
-        const uint32_t room = min(high_room, low_room) * 2;
-        const uint32_t big = high_room > low_room ? val - low_room + pr : pr - val + high_room - 1;
-        const uint32_t small = (val & 1u) ? pr - (val + 1) / 2 : pr + val / 2;
-        const uint32_t fn = val == 0 ? pr : (val >= room ? big : small);
-        const uint32_t touched = (1u << lo) | (1u << hi) | (1u << i);  // lo, hi < i < 32
-        flags |= val != 0 ? touched : 0u;
-        bad = bad || !ok;
-        fr[i] = bad ? 0u : fn;  // after the first out-of-range prediction the row is dropped; keep the chain tame
-      };
+      // The chain runs on the float form of the prediction's division (exact while |dy| * dx < 2^21: always, for amplitudes in range) and
+      // only NOTES a larger product; a row that saw one (absurd coded values) is redone with the integer division afterwards. No
+      // wave-level vote and no divergent branch inside the chain: ~50 instead of ~70 instructions per post, and the chain is what this
+      // kernel's time is.
       typedef const __attribute__((address_space(4))) u32x16* const_pk4;
-      u32x16 kn = *(const_pk4)(uintptr_t)&fc->pk[2];
-      for (uint32_t i = 2; i < posts; i += 4) {
-        const u32x16 kq = kn;
-        kn = *(const_pk4)(uintptr_t)&fc->pk[i + 4];  // (pk[] has 66 entries)
-        step(i, kq[0], kq[1], kq[2]);
-        if (i + 1 < posts) step(i + 1, kq[4], kq[5], kq[6]);
-        if (i + 2 < posts) step(i + 2, kq[8], kq[9], kq[10]);
-        if (i + 3 < posts) step(i + 3, kq[12], kq[13], kq[14]);
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool exact = attempt == 1;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          fr[4 * j + 0] = win[j].x & 0xFFFFu;
+          fr[4 * j + 1] = win[j].x >> 16;
+          fr[4 * j + 2] = win[j].y & 0xFFFFu;
+          fr[4 * j + 3] = win[j].y >> 16;
+        }
+        flags = 3;
+        bad = false;
+        uint32_t big_acc = 0;
+        auto step = [&](const uint32_t i, const uint32_t kx, const uint32_t ky, const uint32_t kz, const uint32_t touched) {
+          const uint32_t lo = kx & 0xFFFFu, hi = kx >> 16;
+          const uint32_t val = fr[i], ylo = fr[lo], yhi = fr[hi];
+          const uint32_t dxi = ky & 0xFFFFu, adx = ky >> 16;
+          const bool up = yhi >= ylo;
+          const uint32_t ady = up ? yhi - ylo : ylo - yhi;
+          const uint32_t prod = ady * dxi;
+          uint32_t off;
+          if (exact) {
+            off = prod / adx;
+          } else {
+            off = (uint32_t)(((float)prod + 0.5f) * __uint_as_float(kz));  // == prod / adx while prod < 2^21 (vsyn_staged.h, predict_post)
+            big_acc |= prod >> 21;
+          }
+          const uint32_t predicted = up ? ylo + off : ylo - off;
+          const bool ok = predicted <= range;  // hpp:536
+          const uint32_t pr = ok ? predicted : 0u;
+          // hpp:540-556 without branches: m = the smaller room; beyond 2 m the value counts linearly from the nearer edge (d resp. -d - 1),
+          // below it it is the zig-zag code of the offset (even: + val / 2, odd: - (val + 1) / 2 = ~(val >> 1))
+          const uint32_t high_room = range - pr;
+          const uint32_t m = min(high_room, pr);
+          const uint32_t d = val - m;
+          const uint32_t dbig = high_room > pr ? d : ~d;
+          const uint32_t dsmall = (val >> 1) ^ (0u - (val & 1u));
+          const uint32_t delta = val >= 2u * m ? dbig : dsmall;
+          const uint32_t fn = val == 0 ? pr : pr + delta;
+          flags |= val != 0 ? touched : 0u;  // (1 << lo) | (1 << hi) | (1 << i), from the table
+          bad = bad || !ok;
+          fr[i] = bad ? 0u : fn;  // after the first out-of-range prediction the row is dropped; keep the chain tame
+        };
+        u32x16 kn = *(const_pk4)(uintptr_t)&fc->pk[2];
+        for (uint32_t i = 2; i < posts; i += 4) {
+          const u32x16 kq = kn;
+          kn = *(const_pk4)(uintptr_t)&fc->pk[i + 4];  // (pk[] has 66 entries)
+          step(i, kq[0], kq[1], kq[2], kq[3]);
+          if (i + 1 < posts) step(i + 1, kq[4], kq[5], kq[6], kq[7]);
+          if (i + 2 < posts) step(i + 2, kq[8], kq[9], kq[10], kq[11]);
+          if (i + 3 < posts) step(i + 3, kq[12], kq[13], kq[14], kq[15]);
+        }
+        if (exact || !__any(big_acc != 0u)) break;
+        if (big_acc == 0u) break;  // (only the rows that saw a large product are redone)
       }
       uint2* out8 = (uint2*)(A.fy + gid * stride);
       if (bad) raise_status(A.status, VSYN_ST_FLOOR_RANGE, p);
@@ -324,6 +347,13 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
     }
     return;
   }
+  const uint32_t ce = min(num, run1 * R);  // one past the chunk's last packet (<= cs: the chunk lies beyond the segment's end)
+  const vsyn_packet* const spk = A.packets + sg.first_packet;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t num_modes = H->num_modes, bs0 = H->bs[0], bs1 = H->bs[1];
+  const uint64_t long_modes = A.long_modes;
+#define PREP_IS_LONG(m) ((m) < num_modes && (m) < 64u && ((long_modes >> (m)) & 1ull))
+#define PREP_N_OF_MODE(m) (PREP_IS_LONG(m) ? bs1 : bs0)
   uint32_t st_slot;
   const StreamState st0 = state_read(A.state, sg.stream, A.epoch, &st_slot);
   const bool reset = (sg.flags & VSYN_SEG_RESET) != 0;
@@ -343,13 +373,6 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
     return;
   }
   PSTAMP(0);  // header fields, stream state
-  const uint32_t ce = min(num, run1 * R);  // one past the chunk's last packet
-  const vsyn_packet* const spk = A.packets + sg.first_packet;
-  const uint32_t num_modes = H->num_modes, bs0 = H->bs[0], bs1 = H->bs[1];
-  const uint64_t long_modes = A.long_modes;
-#define PREP_IS_LONG(m) ((m) < num_modes && (m) < 64u && ((long_modes >> (m)) & 1ull))
-#define PREP_N_OF_MODE(m) (PREP_IS_LONG(m) ? bs1 : bs0)
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
   // ---- 1. the scan's values in front of the chunk: every workgroup reduces the segment's earlier descriptors for itself (a thread a
   //         contiguous piece, one block scan) instead of waiting for a predecessor — that is what makes the kernel dependency-free ------

@@ -347,6 +347,30 @@ def test_garbage_descriptors_and_posts(flags):
         orc = ob.OracleSynth(spec, 3)
 
 
+@pytest.mark.parametrize("bs0,bs1", [(256, 2048), (128, 1024)])
+def test_absurd_coded_posts_unwrap_alike_on_every_preparation(bs0, bs1):
+    """Coded floor values far outside a valid stream's range (up to 65535: |dy| * dx beyond 2^21, where the preparation kernel's float
+    form of hpp:533's division is no longer exact and the row is redone with the integer division): `floor_final` of the
+    dependency-free preparation kernel == the chained pre-kernels == the staged path, bit for bit, flagged rows included; and equal
+    to the oracle's rows wherever the oracle raises nothing."""
+    spec = fixture_like_spec(2, bs0, bs1)
+    b = synth_batch(spec, 3, 40, "mixed", seed=31)
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        ys = b["ys"].copy()
+        yh = rng.random(ys.shape) < (0.02 if trial < 2 else 0.3)
+        ys[yh] = rng.integers(0, 65536 if trial % 2 else 4096, int(yh.sum()))
+        rows = []
+        for flags in PATHS:
+            gpu = binding.Synth(spec, max_streams=3)
+            r = gpu.submit_host(b["packets"], b["segments"], ys, b["residue"], b["plane_stride"], flags=flags, want_taps="features")
+            rows.append(r["taps"]["floor_final"])
+        assert np.array_equal(rows[0], rows[1]) and np.array_equal(rows[0], rows[2]), trial
+        w = ob.OracleSynth(spec, 3).submit_host(b["packets"], b["segments"], ys, b["residue"], b["plane_stride"], want_taps=True)
+        if w["rc"] == 0:
+            assert np.array_equal(rows[0], w["taps"]["floor_final"]), trial
+
+
 @pytest.mark.parametrize("pattern,C,bs0,bs1", [("long", 2, 256, 2048), ("mixed", 2, 256, 2048), ("mixed", 1, 256, 2048),
                                                ("mixed", 2, 128, 1024), ("long", 2, 128, 1024), ("mixed", 3, 128, 1024),   # size-generic kernel
                                                ("mixed", 2, 512, 4096), ("mixed", 1, 64, 8192), ("mixed", 2, 1024, 2048)])  # ... its register sets; both kernels
