@@ -683,10 +683,11 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   //       dependency-free kernel (vsyn_prep.h, ~20 us) in front of the synthesis kernel on the caller's stream; no second queue, no
   //       events. Else (staged kernels, intermediate-signal taps, the residue VQ stage — its kernel needs the packets' offsets first —,
   //       very long segments, VSYN_SUBMIT_PRE_KERNELS) the layout and unwrap kernels there.
-  //   Round 3 measured (b) for device-resident pipelines too (VSYN_PREP_SERIAL=1): config 3 0.2592 vs 0.2586 ms per step, config 4
-  //   0.0877 vs 0.0860, 128/1024 0.226 vs 0.200 — the hidden pre-kernels win or tie everywhere, so (a) stays the default there; and
-  //   the preparation kernel on the internal stream (VSYN_PREP_OVERLAP=1): 0.266 ms, its 256-thread / 121-VGPR workgroups cost the
-  //   exact-fit synthesis grid more than the two small kernels do. (b) is what the host-buffer entry points get: 20 instead of ~35 us.
+  //   Round 3 measured (b) for device-resident pipelines too (VSYN_PREP_SERIAL=1): config 3 0.254-0.262 vs 0.256-0.259 ms per step,
+  //   config 4 0.084-0.088 vs 0.081-0.086 — the hidden pre-kernels win or tie on the 256/2048 kernel, so (a) stays the default there;
+  //   the preparation kernel on the internal stream (VSYN_PREP_OVERLAP=1): 0.266 ms, its 256-thread workgroups cost the exact-fit
+  //   synthesis grid more than the two small kernels do. (b) is what the host-buffer entry points get (19 instead of ~35 us) — and,
+  //   see below, every submit of the size-generic kernel <1>.
   static const bool env_no_prep_kernel = getenv("VSYN_NO_PREP_KERNEL") && atoi(getenv("VSYN_NO_PREP_KERNEL"));
   // VSYN_PREP_SERIAL: 1 = (b) for VSYN_SUBMIT_INPUTS_READY submits too, 0 = never; unset = where it measured faster: setups whose runs
   // all go to the size-generic kernel (its 16-wave workgroups fill a CU's registers exactly: hidden pre-kernels have to wait for its

@@ -68,7 +68,7 @@ struct UArgs {
                             // the two channel waves swap rows pairwise; 3 anything else (<= U_MAX_CH channels, any coupling list per
                             // mapping): the channel waves of a run replay the steps in place, in order
 };
-#define U_MAX_CH 12u
+#define U_MAX_CH 16u  /* coupled channels: the channel waves of a run share one workgroup (16 waves; 8 for blocks above 2048) */
 
 __device__ __forceinline__ void u_dft4(float2& x0, float2& x1, float2& x2, float2& x3) {  // natural order, forward
   const float2 a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = mul_mi(csub(x1, x3));
@@ -1077,7 +1077,8 @@ struct UTables {
 static inline uint32_t u_role_mode(const ConstHeader& H, const uint8_t* host_const);
 static inline bool u_supported(const ConstHeader& H, const uint8_t* host_const) {
   // blocksize1 up to 8192 (register sets, UBig); blocksize0 must fit the packed passes. The channel waves of a run share one workgroup
-  // (12 waves) when any mapping couples channels; a setup without coupling steps has no such tie: any channel count.
+  // (16 waves, 8 with blocks above 2048: u_tables_create turns a setup down that does not fit) when any mapping couples channels; a
+  // setup without coupling steps has no such tie: any channel count.
   // (a blocksize0 above 2048 only when it equals blocksize1: every block then takes the register-set path, whatever its mode says)
   if ((H.bs[0] > 2048 && H.bs[0] != H.bs[1]) || (H.channels > U_MAX_CH && u_role_mode(H, host_const) != 0u)) return false;
   const FloorConst* fl = (const FloorConst*)(host_const + H.off_floor);

@@ -594,14 +594,17 @@ def test_equal_block_sizes_above_2048_stay_fused(C, bs, pattern):
     check(gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"], flags=binding.VSYN_SUBMIT_STAGED), want)
 
 
-def test_more_than_12_coupled_channels_take_the_staged_kernels():
-    """The channel waves of a coupled run share one workgroup (12 waves): 13+ channels WITH a coupling step are the one channel layout
-    left to the staged kernels — asserted, and still equal to the oracle."""
-    base = fixture_like_spec(1, 128, 1024)
-    spec = SetupSpec(14, 128, 1024, base.floors, [([(0, 13)], [0] * 14), ([(0, 13)], [1] * 14)], [(0, 0), (1, 1)])
-    b = synth_batch(spec, 2, 21, "mixed", seed=14, unused_frac=0.2, granule_last=True)
+@pytest.mark.parametrize("C,bs0,bs1,paths", [(14, 128, 1024, 2), (16, 256, 2048, 2), (17, 128, 1024, 0), (14, 512, 4096, 0)])
+def test_many_coupled_channels(C, bs0, bs1, paths):
+    """The channel waves of a COUPLED run share one workgroup — 16 waves of the size-generic kernel, 8 where blocks above 2048 need
+    register sets: up to that many coupled channels stay fused, one more is the channel layout left to the staged kernels. Asserted
+    either way, and equal to the oracle."""
+    base = fixture_like_spec(1, bs0, bs1)
+    coup = [(0, C - 1), (1, 2)]
+    spec = SetupSpec(C, bs0, bs1, base.floors, [(coup, [0] * C), (coup, [1] * C)], [(0, 0), (1, 1)])
+    b = synth_batch(spec, 2, 21, "mixed", seed=C, unused_frac=0.2, granule_last=True)
     gpu = binding.Synth(spec, max_streams=2)
-    assert gpu.fused_paths == 0, gpu.fused_paths
+    assert gpu.fused_paths == paths, gpu.fused_paths
     want = ob.OracleSynth(spec, 2).submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"])
     check(gpu.submit_host(b["packets"], b["segments"], b["ys"], b["residue"], b["plane_stride"]), want)
 

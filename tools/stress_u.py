@@ -32,7 +32,7 @@ for seed in range(first, first + count):
               (int(rng.integers(1, 5)), xs(bs1 // 2, 65 if rng.random() < 0.15 else int(rng.integers(2, 65))))]
     def coup():
         out = []
-        for _ in range(int(rng.integers(0, 4)) if 1 < C <= 12 else 0):  # (13+ channels: uncoupled, the layout that stays fused)
+        for _ in range(int(rng.integers(0, 4)) if 1 < C <= (16 if bs1 <= 2048 else 8) else 0):  # (more channels than a workgroup has waves: uncoupled, the layout that stays fused)
             m, a = rng.choice(C, 2, replace=False)
             out.append((int(m), int(a)))
         return out
