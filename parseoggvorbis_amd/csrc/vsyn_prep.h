@@ -6,7 +6,9 @@
 // between two synthesis kernels; tools/stream_sync_bench.hip: no cheaper ordering primitive, hipExtAnyOrderLaunch is ignored on this
 // part) and their waves compete with an exact-fit synthesis grid for wave slots (+6 us on the synthesis kernel). This kernel is short
 // enough to simply run IN FRONT of the synthesis kernel on the caller's stream: a submit is two launches on one queue, no second
-// queue, no events.
+// queue, no events. Who gets it (vorbis_synth_hip.hip, submit_device_impl): every submit without VSYN_SUBMIT_INPUTS_READY, and with it
+// the submits of the size-generic kernel <1>, where it measured 2-4 % faster per step than the hidden pre-kernels; the 256/2048 kernel
+// keeps the hidden pre-kernels for device-resident pipelines (a tie on config 3, 3-4 % better on config 4).
 //
 // One wave per (segment, run [qa, qb) of the synthesis kernels, channel c); lane j <-> packet qa + j:
 //   1. the scan's running values in front of the run — absolute position (granule-aware, hpp:1028-1044), residue offset, block size —
@@ -16,8 +18,8 @@
 //      chunked scan);
 //   2. PktInfo of the run's packets by a wave scan (pkt_step, shared with the layout kernel), emit_len, the run's class from a ballot
 //      over its block flags (channel 0's wave writes them);
-//   3. floor-1 step 1 (hpp:521-559), one lane per (packet, channel) row, the row's posts in LDS, four independent posts at a time
-//      (prep_unwrap_rows);
+//   3. floor-1 step 1 (hpp:521-559), one lane per (packet, channel) row (prep_unwrap_rows): floors of up to 32 posts as a branch-free
+//      chain over a register array, longer ones with the row's posts in LDS, four independent posts at a time;
 //   4. the wave of a segment's last run (channel 0) leaves the stream state for the next submit (tagged records, vsyn_device.h) and
 //      the segment's SegInfo.
 #pragma once
@@ -111,8 +113,10 @@ __device__ __forceinline__ void prep_unwrap_rows(const PrepCtx& A, const bool ac
     if (posts <= 32u) {
       // Up to 32 posts (every floor libvorbis writes for the common modes): the row in a register array indexed by the wave-uniform
       // neighbour numbers, one post at a time in header order, the per-post constants by scalar loads of four posts, one load ahead.
-      // Measured on config 3 (29 posts, two waves per SIMD): 620 cycles per post; the grouped forms below / with this array cost 1.7x /
-      // 2x that per post (an access to the array is an s_set_gpr_idx mode switch; four chains side by side do not make up for it).
+      // Measured on config 3 (29 posts, two waves per SIMD): 620 cycles per post with round 3's first form of the chain (~70 instructions
+      // per post, a wave vote and two divergent branches in it), the kernel 20.7 us; 19.3 us with the form below. The grouped forms
+      // further down / with this array cost 1.7x / 2x per post (an access to the array is an s_set_gpr_idx mode switch; four chains
+      // side by side do not make up for it).
       uint32_t fr[32];
       const uint2* in8 = (const uint2*)(A.ys + gid * stride);
       uint2 win[8];
