@@ -327,7 +327,11 @@ def main():
                          "seeded batch, the PCM is gathered over the process group (sharding.gather_pcm) and rank 0 checks every stream "
                          "against the oracle")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="do not let a submit's pre-kernels overlap the previous submit (diagnostic: standalone kernel times)")
+                    help="submit without VSYN_SUBMIT_INPUTS_READY (diagnostic: nothing of a submit may overlap the previous one)")
+    ap.add_argument("--hidden-pre-kernels", action="store_true",
+                    help="A/B: prepare every batch with the chained layout + unwrap kernels on the library's internal stream, hidden beside "
+                         "the previous submit's synthesis kernel (the default of rounds 1-3) instead of the preparation kernel on the "
+                         "caller's stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -380,6 +384,9 @@ def main():
     # the synthetic descriptors are resident and final before the timed region: consecutive submits may overlap their
     # pre-kernels with the previous synthesis kernel (every kernel of every step still runs inside the timed region)
     flags = VSYN_SUBMIT_STAGED if args.staged else (0 if args.no_overlap else VSYN_SUBMIT_INPUTS_READY)
+    if args.hidden_pre_kernels and not args.staged:
+        from parseoggvorbis_amd.binding import VSYN_SUBMIT_PRE_KERNELS
+        flags = VSYN_SUBMIT_INPUTS_READY | VSYN_SUBMIT_PRE_KERNELS
 
     if args.workload == "config2":
         n, count = 256, 4096

@@ -141,12 +141,14 @@ typedef struct vsyn_handle vsyn_handle;
 /* submit flags */
 #define VSYN_SUBMIT_STAGED 1u         /* force the staged (tap-capable, any-shape) kernels instead of the fused one */
 #define VSYN_SUBMIT_INPUTS_READY 2u   /* vsyn_submit_device: packets/segments/ys are complete already (not produced by work still
-                                         pending on hip_stream). Lets the layout + floor-unwrap kernels of this submit overlap the
-                                         synthesis kernel of the previous one; results are identical either way. */
+                                         pending on hip_stream). Where a submit's preparation consists of the chained layout + floor-unwrap
+                                         kernels (staged work, the VQ stage, very long segments, VSYN_SUBMIT_PRE_KERNELS), this lets them
+                                         overlap the synthesis kernel of the previous submit; results are identical either way. */
 
 #define VSYN_SUBMIT_PRE_KERNELS 8u    /* diagnostics / A-B: prepare the batch (layout scan, floor-1 step 1) with the two chained kernels also
-                                         where the single dependency-free preparation kernel would be used (submits without
-                                         VSYN_SUBMIT_INPUTS_READY whose runs are all taken by the fused kernels); results are identical. */
+                                         where the single dependency-free preparation kernel is the default (submits whose runs are all
+                                         taken by the fused kernels); with VSYN_SUBMIT_INPUTS_READY they run hidden beside the previous
+                                         submit's synthesis kernel (the default of rounds 1-3 for such submits); results are identical. */
 #define VSYN_SUBMIT_KEEP_PCM 4u        /* vsyn_submit_host*: leave the PCM on the device (`pcm` may be NULL, nothing is copied back);
                                          fetch it in the form the consumer wants with vsyn_pcm_fetch_host */
 

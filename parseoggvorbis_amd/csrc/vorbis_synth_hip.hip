@@ -470,20 +470,32 @@ void vsyn_destroy(vsyn_handle* h) {
   }
 #endif
 #ifdef PREP_STAMPS
-  {  // diagnostic build: cycles per phase of the in-wave preparation (last launch), averaged over the waves that ran one
+  {  // diagnostic build: cycles per phase of vsyn_prep_kernel (last launch), averaged over the waves of each role, and when the waves
+     // of each role started / ended relative to the first wave of the launch (100 MHz clock)
     static unsigned long long host[8192][PREP_NSTAMPS];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prep_stamps), sizeof(host)) == hipSuccess) {
-      double sum[PREP_NSTAMPS] = {0};
-      unsigned long long waves = 0;
-      for (int u = 0; u < 8192; ++u) {
-        if (!host[u][PREP_NSTAMPS - 1]) continue;
-        ++waves;
-        for (int i = 0; i + 1 < PREP_NSTAMPS; ++i) sum[i] += (double)host[u][i];
-      }
-      if (waves) {
-        static const char* nm[PREP_NSTAMPS - 1] = {"header + stream state", "scan in front of the run", "descriptors, scan, PktInfo", "floor-1 step 1", "drain + invalidate", "-", "-"};
-        fprintf(stderr, "prep stamps: %llu waves\n", waves);
-        for (int i = 0; i + 1 < PREP_NSTAMPS; ++i) fprintf(stderr, "  %-28s %8.0f cycles\n", nm[i], sum[i] / waves);
+      unsigned long long t_first = ~0ull;
+      for (int u = 0; u < 8192; ++u)
+        if (host[u][7] && host[u][5] < t_first) t_first = host[u][5];
+      for (unsigned role = 0; role < 2; ++role) {
+        double sum[5] = {0}, st = 0, en = 0, en_max = 0, st_max = 0;
+        unsigned long long waves = 0;
+        for (int u = 0; u < 8192; ++u) {
+          if (host[u][7] != 1ull + role) continue;
+          ++waves;
+          for (int i = 0; i < 5; ++i) sum[i] += (double)host[u][i];
+          const double a = (double)(host[u][5] - t_first) / 100.0, b = (double)(host[u][6] - t_first) / 100.0;
+          st += a;
+          en += b;
+          if (a > st_max) st_max = a;
+          if (b > en_max) en_max = b;
+        }
+        if (!waves) continue;
+        static const char* nm[5] = {"header + stream state", "scan in front of the chunk", "descriptors, scan, PktInfo", "floor role: descriptors, floor ids", "floor role: chains"};
+        fprintf(stderr, "prep stamps, %s role: %llu waves; start %.2f us (latest %.2f), end %.2f us (latest %.2f) after the launch's first wave\n",
+                role ? "floor" : "layout", waves, st / waves, st_max, en / waves, en_max);
+        for (int i = 0; i < 5; ++i)
+          if (sum[i] > 0) fprintf(stderr, "  %-36s %8.0f cycles\n", nm[i], sum[i] / waves);
       }
     }
   }
@@ -676,25 +688,22 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
   uint32_t* list = h->ws_list[wb].p;
 
   // Preparation of the batch (layout scan, floor-1 step 1): two ways.
-  //   (a) With VSYN_SUBMIT_INPUTS_READY: the layout kernel and the unwrap kernel on the internal stream `pre`, beside the previous
-  //       submit's synthesis kernel — their ~35 us of dependent latency are hidden, at the price of one event record and one
-  //       cross-queue wait per submit (~15 us between two synthesis kernels) and ~6 us of interference with the synthesis grid.
-  //   (b) Otherwise, when every run is taken by a fused kernel and no segment is longer than PREP_MAX_SEG_PACKETS: ONE
-  //       dependency-free kernel (vsyn_prep.h, ~20 us) in front of the synthesis kernel on the caller's stream; no second queue, no
-  //       events. Else (staged kernels, intermediate-signal taps, the residue VQ stage — its kernel needs the packets' offsets first —,
-  //       very long segments, VSYN_SUBMIT_PRE_KERNELS) the layout and unwrap kernels there.
-  //   Round 3 measured (b) for device-resident pipelines too (VSYN_PREP_SERIAL=1): config 3 0.254-0.262 vs 0.256-0.259 ms per step,
-  //   config 4 0.084-0.088 vs 0.081-0.086 — the hidden pre-kernels win or tie on the 256/2048 kernel, so (a) stays the default there;
-  //   the preparation kernel on the internal stream (VSYN_PREP_OVERLAP=1): 0.266 ms, its 256-thread workgroups cost the exact-fit
-  //   synthesis grid more than the two small kernels do. (b) is what the host-buffer entry points get (19 instead of ~35 us) — and,
-  //   see below, every submit of the size-generic kernel <1>.
+  //   (a) vsyn_prep_kernel (vsyn_prep.h): ONE dependency-free kernel — layout workgroups and floor workgroups side by side, ~17 us — in
+  //       front of the synthesis kernel on the caller's stream; no second queue, no events. The default whenever every run is taken by
+  //       a fused kernel and no segment is longer than PREP_MAX_SEG_PACKETS.
+  //   (b) The chained layout and unwrap kernels (vsyn_staged.h): for staged work lists, intermediate-signal taps, the residue VQ stage
+  //       (its kernel needs the packets' offsets first), very long segments, VSYN_SUBMIT_PRE_KERNELS. With VSYN_SUBMIT_INPUTS_READY
+  //       they run on the internal stream `pre`, beside the previous submit's synthesis kernel: their ~35 us of dependent latency are
+  //       hidden, at the price of one event record and one cross-queue wait per submit (~15 us between two synthesis kernels) and ~6 us
+  //       of interference with an exact-fit synthesis grid.
+  //   Until late in round 3 (b)-hidden was the default for VSYN_SUBMIT_INPUTS_READY: against a 20 us preparation kernel it tied on
+  //   config 3 (0.256-0.259 ms per step either way) and won config 4 by 3 %. With the preparation's two halves running side by side
+  //   (a) wins everywhere measured: config 3 0.2540 vs 0.2572 ms, config 4 0.0796 vs 0.0823, 128/1024 0.187 vs 0.195 (same box,
+  //   profiles/r03_experiments/batch_preparation_ab.txt). VSYN_PREP_SERIAL=0 brings (b)-hidden back for such submits, for A/B runs; the
+  //   preparation kernel on the internal stream (VSYN_PREP_OVERLAP=1) lost to both (0.266 ms).
   static const bool env_no_prep_kernel = getenv("VSYN_NO_PREP_KERNEL") && atoi(getenv("VSYN_NO_PREP_KERNEL"));
-  // VSYN_PREP_SERIAL: 1 = (b) for VSYN_SUBMIT_INPUTS_READY submits too, 0 = never; unset = where it measured faster: setups whose runs
-  // all go to the size-generic kernel (its 16-wave workgroups fill a CU's registers exactly: hidden pre-kernels have to wait for its
-  // tail, and the single-queue form is 2-4 % faster per step on every such workload measured — 128/1024, 256/512, 512/512, 1024/1024,
-  // long and mixed; profiles/r03_experiments/generic_kernel_16_waves.txt).
   static const int env_prep_serial_mode = getenv("VSYN_PREP_SERIAL") ? (atoi(getenv("VSYN_PREP_SERIAL")) ? 1 : 0) : -1;
-  const bool env_prep_serial = env_prep_serial_mode == 1 || (env_prep_serial_mode < 0 && use_u && !(fmask & 1u) && h->utab.ns == 1);
+  const bool env_prep_serial = env_prep_serial_mode != 0;
   static const bool env_prep_overlap = getenv("VSYN_PREP_OVERLAP") && atoi(getenv("VSYN_PREP_OVERLAP"));
   const bool prep_ok = !force_staged && (fmask & 2u) && !d_vq && max_seg_packets <= PREP_MAX_SEG_PACKETS && !(flags & VSYN_SUBMIT_PRE_KERNELS) && !env_no_prep_kernel;
   const bool overlap_pre = (flags & VSYN_SUBMIT_INPUTS_READY) && !force_staged && !(env_prep_serial && prep_ok);
@@ -784,7 +793,8 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     const uint32_t ppp = std::max<uint32_t>(1u, PREP_THREADS / C);
     pc.chunk_runs = std::max<uint32_t>(1u, ppp / R);
     pc.chunks_per_seg = (runs_per_seg + pc.chunk_runs - 1u) / pc.chunk_runs;
-    const uint64_t wgs = (uint64_t)S * pc.chunks_per_seg;
+    // a layout workgroup and a floor workgroup per (segment, chunk), dealt in alternating groups of eight (vsyn_prep.h)
+    const uint64_t wgs = (((uint64_t)S * pc.chunks_per_seg + 7u) / 8u) * 16u;
     if (wgs > 0x7FFFFFF0ull) return fail(err, VSYN_ERR_INVALID, "too many runs");
     vsyn_prep_kernel<<<(uint32_t)wgs, PREP_THREADS, h->prep_lds_bytes, ps>>>(pc);
   }

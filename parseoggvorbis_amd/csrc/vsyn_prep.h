@@ -322,19 +322,41 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];  // [posts of the longest floor, rounded up to 4][PREP_THREADS]: prep_unwrap_rows
   __shared__ AbsScan s_abs[PREP_WAVES];
   __shared__ uint64_t s_res[PREP_WAVES];
-  __shared__ uint32_t s_pk[PREP_THREADS];      // per packet of the pass: own | mapping << 16 | bad << 24 (floor_used beyond 16 channels: see below)
-  __shared__ uint32_t s_own[PREP_THREADS];     // per packet of the pass: the full floor_used mask after the channel mask
+  __shared__ uint32_t s_pk[PREP_THREADS];      // block size of each packet of the pass (a packet needs its predecessor's)
   __shared__ uint32_t s_longbits[PREP_MAX_SEG_PACKETS / 32 + 2];  // bit 0: the packet in front of the chunk, bit 1 + i: packet cs + i — set = a valid long block
   __shared__ uint32_t s_last_n;
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const uint32_t C = H->channels;
-  const uint32_t g = blockIdx.x / A.chunks_per_seg, ch = blockIdx.x % A.chunks_per_seg;
+  // Two kinds of workgroup per (segment, chunk), dealt alternately so that both start at once: even blockIdx = the LAYOUT of the chunk's
+  // packets (scan, PktInfo, run classes, stream state), odd = FLOOR-1 STEP 1 of their rows ("even / odd" in the sense spelled out below). The rows need nothing the scan produces —
+  // which floor and whether the channel carries a curve follow from the packet's own descriptor — so the two halves of the preparation,
+  // ~13 k and ~16 k cycles of dependent work, run side by side instead of one behind the other.
+  // Dealing: consecutive workgroups go to consecutive XCDs, and inside an XCD consecutive ones to consecutive CUs (32 of them) — a plain
+  // even / odd split would put every floor workgroup on four of the eight XCDs, and one by the XCD-local index j alone every floor
+  // workgroup on every other CU. So: the pair (2m, 2m + 1) of XCD-local indices serves chunk 8 m + xcd, and which of the two is the
+  // floor workgroup flips with j / 32: a CU's four workgroups j = k, k + 32, k + 64, k + 96 are two of each kind.
+  const uint32_t xj = blockIdx.x >> 3;
+  const uint32_t role = (xj ^ (xj >> 5)) & 1u, bid = ((xj >> 1) << 3) | (blockIdx.x & 7u);
+  const uint32_t g = bid / A.chunks_per_seg, ch = bid % A.chunks_per_seg;
   if (g >= A.S) return;
 #ifdef PREP_STAMPS
   unsigned long long pst_acc[PREP_NSTAMPS] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long pst_last = __builtin_readcyclecounter();
+  const unsigned long long pst_t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock: when this wave started
+#define PSTAMP_FLUSH()                                                                                              \
+  do {                                                                                                              \
+    const uint32_t unit_ = blockIdx.x * PREP_WAVES + wave;                                                          \
+    if (lane == 0 && unit_ < 8192) {                                                                                \
+      for (int i_ = 0; i_ < 5; ++i_) g_prep_stamps[unit_][i_] = pst_acc[i_];                                        \
+      g_prep_stamps[unit_][5] = pst_t0;                                                                             \
+      g_prep_stamps[unit_][6] = __builtin_amdgcn_s_memrealtime();                                                   \
+      g_prep_stamps[unit_][7] = 1ull + role;                                                                        \
+    }                                                                                                               \
+  } while (0)
+#else
+#define PSTAMP_FLUSH() do { } while (0)
 #endif
   const vsyn_segment sg = A.segs[g];
   const uint32_t num = sg.num_packets;
@@ -344,6 +366,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   const uint32_t cs = run0 * R;                                     // first packet of the chunk
   uint8_t* const cls_row = A.run_cls + (size_t)g * A.runs_per_seg;
   if (sg.stream >= H->max_streams || (uint64_t)sg.first_packet + sg.num_packets > A.P || (sg.residue_off & 3)) {
+    if (role) return;
     for (uint32_t r = run0 + t; r < run1; r += PREP_THREADS) cls_row[r] = 0xFFu;
     if (ch == 0u && t == 0u) {
       raise_status(A.status, VSYN_ST_BAD_SEGMENT, sg.first_packet < A.P ? sg.first_packet : 0);
@@ -358,6 +381,53 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   const uint64_t long_modes = A.long_modes;
 #define PREP_IS_LONG(m) ((m) < num_modes && (m) < 64u && ((long_modes >> (m)) & 1ull))
 #define PREP_N_OF_MODE(m) (PREP_IS_LONG(m) ? bs1 : bs0)
+  if (role) {
+    // ---- floor-1 step 1 of the chunk's rows: thread <-> row (packet base + t / C, channel t % C) ---------------------------------------
+    const uint32_t ce = min(num, run1 * R);
+    if (cs >= ce) return;
+    const vsyn_packet* const spk = A.packets + sg.first_packet;
+    const uint32_t stride = __builtin_amdgcn_readfirstlane(H->ys_stride);
+    const MapConst* const maps = (const MapConst*)(cb + H->off_map);
+    const uint32_t chan_mask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
+    const uint32_t num_modes = H->num_modes;
+    const uint32_t ppp = PREP_THREADS / C;
+    for (uint32_t base = cs; base < ce; base += ppp) {
+      const uint32_t pe = min(ce, base + ppp);
+      const uint32_t rp = t / C, c = t - rp * C;
+      const bool row_ok = rp < pe - base;
+      uint32_t kmode = 0xFFFFFFFFu, fused_mask = 0;
+      if (row_ok) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = *(const u32x2*)(spk + base + rp);  // mode | window flags, floor_used
+        kmode = w.x & 0xFFu;
+        fused_mask = w.y;
+      }
+      const bool mode_ok = row_ok && kmode < num_modes;
+      // which floor: mode -> mapping -> the channel's floor, one DISTINCT mode of the wave at a time through the scalar unit
+      uint32_t fl_id = 0xFFFFFFFFu;
+      {
+        typedef const __attribute__((address_space(4))) uint32_t* kptr;
+        uint64_t todo = __ballot(mode_ok);
+        while (todo) {
+          const uint32_t m = __builtin_amdgcn_readlane(kmode, (uint32_t)__builtin_ctzll(todo));
+          const bool mine = mode_ok && kmode == m;
+          todo &= ~__ballot(mine);
+          const uint32_t mw = *(kptr)(uintptr_t)((const uint8_t*)H->mode_mapping + (m & ~3u));
+          const uint32_t mp = (mw >> (8u * (m & 3u))) & 0xFFu;
+          if (mine) fl_id = maps[mp].chfloor[c];
+        }
+      }
+      // a row is unwrapped when its packet names a valid mode and carries a curve for the channel (hpp:1159); packets the scan will
+      // flag for their granule or for plane overflow are unwrapped too — the reference decodes the floor before it gets there as well
+      const bool act = mode_ok && (((fused_mask & chan_mask) >> c) & 1u);
+      const uint32_t prow = sg.first_packet + base + rp;
+      PSTAMP(3);  // floor role: descriptors, floor numbers
+      prep_unwrap_rows(A, act, fl_id, prow, (size_t)prow * C + c, stride, (prep_lds_u32*)s_rows);
+      PSTAMP(4);  // floor role: the chains
+    }
+    PSTAMP_FLUSH();
+    return;
+  }
   uint32_t st_slot;
   const StreamState st0 = state_read(A.state, sg.stream, A.epoch, &st_slot);
   const bool reset = (sg.flags & VSYN_SEG_RESET) != 0;
@@ -446,7 +516,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
     const uint32_t lng = (valid && PREP_IS_LONG(kmode)) ? 1u : 0u;
     const uint32_t n = lng ? bs1 : bs0;
     // block size in front of each packet: the previous thread's (across the wave boundary through LDS)
-    __syncthreads();  // s_pk / s_own / s_longbits of the previous pass are no longer read
+    __syncthreads();  // s_pk of the previous pass is no longer read
     s_pk[t] = n;
     __syncthreads();
     const uint32_t prev_n = t == 0u ? prev_n_in : s_pk[t - 1u];
@@ -482,7 +552,6 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
     const int64_t abs_before = ex.set ? ex.val : abs0 + ex.val;
     const uint64_t res_off = sg.residue_off + cres + rex;
     const uint32_t p = sg.first_packet + q;
-    uint32_t pk_word = 0x01000000u, own_word = 0u;  // (bad until shown otherwise: rows of a packet beyond the pass are never unwrapped)
     // mode -> mapping and the nonzero propagate over the mapping's coupling steps (hpp:1174-1180), one DISTINCT mode of the wave at a
     // time: everything about a mode then comes through the scalar unit (a wave rarely sees more than two modes) instead of three
     // dependent per-lane loads
@@ -531,28 +600,11 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
         ns.tag = 0;
         state_write(A.state, sg.stream, st_slot, ns, A.epoch);
       }
-      pk_word = (uint32_t)ps.pi.mapping << 16 | (uint32_t)ps.pi.bad << 24;
-      own_word = ps.pi.own & chan_mask;
       if (mode_ok && lng) atomicOr(&s_longbits[(q - cs + 1u) >> 5], 1u << ((q - cs + 1u) & 31u));
       if (q == pe - 1u) s_last_n = n;
     }
-    __syncthreads();  // everyone has read its predecessor's block size
-    s_pk[t] = pk_word;
-    s_own[t] = own_word;
-    __syncthreads();
+    __syncthreads();  // s_last_n is in place; everyone has read its predecessor's block size
     PSTAMP(2);  // descriptors, block scan, PktInfo
-    // ---- 3. floor-1 step 1: thread <-> row (packet base + t / C, channel t % C) -----------------------------------------------------------
-    {
-      const uint32_t rp = t / C, c = t - rp * C;
-      const bool row_ok = rp < pe - base;
-      const uint32_t pw = row_ok ? s_pk[rp] : 0x01000000u, ow = row_ok ? s_own[rp] : 0u;
-      const bool act = row_ok && !(pw >> 24) && ((ow >> c) & 1u);
-      uint32_t fl_id = 0xFFFFFFFFu;
-      if (act) fl_id = maps[(pw >> 16) & 0xFFu].chfloor[c];
-      const uint32_t prow = sg.first_packet + base + rp;
-      prep_unwrap_rows(A, act, fl_id, prow, (size_t)prow * C + c, stride, (prep_lds_u32*)s_rows);
-    }
-    PSTAMP(3);  // floor-1 step 1
     // carry the scan into the next pass (s_last_n was written before the barriers above)
     cin = abs_combine(cin, tot);
     cres += rtot;
@@ -579,13 +631,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
       cls_row[r] = (uint8_t)cls;
     }
   }
-#ifdef PREP_STAMPS
-  {
-    const uint32_t unit = blockIdx.x * PREP_WAVES + wave;
-    if (lane == 0 && unit < 8192)
-      for (int i = 0; i < PREP_NSTAMPS; ++i) g_prep_stamps[unit][i] = i == PREP_NSTAMPS - 1 ? 1ull : pst_acc[i];
-  }
-#endif
+  PSTAMP_FLUSH();
 #undef PREP_IS_LONG
 #undef PREP_N_OF_MODE
 }

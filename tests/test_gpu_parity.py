@@ -13,7 +13,8 @@ from tests.workloads import fixture_like_spec, load_golden, synth_batch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-PATHS = [0, binding.VSYN_SUBMIT_PRE_KERNELS, binding.VSYN_SUBMIT_STAGED]  # in-wave preparation (default), pre-kernels, staged kernels
+PATHS = [0, binding.VSYN_SUBMIT_PRE_KERNELS, binding.VSYN_SUBMIT_STAGED]  # preparation kernel (default), chained pre-kernels, staged kernels
+HIDDEN_PRE = binding.VSYN_SUBMIT_INPUTS_READY | binding.VSYN_SUBMIT_PRE_KERNELS  # chained pre-kernels on the internal stream
 
 
 def bits(a):
@@ -282,9 +283,11 @@ def test_imdct_only(n):
         assert np.abs(got[r] - cf).max() < TOL * max(1.0, peak)
 
 
-def test_device_resident_back_to_back_submits_overlap_safely():
-    """vsyn_submit_device with VSYN_SUBMIT_INPUTS_READY: consecutive submits overlap their pre-kernels with the previous
-    synthesis kernel on double-buffered workspaces. Different batches back to back, no sync in between, each == oracle."""
+@pytest.mark.parametrize("flags", [binding.VSYN_SUBMIT_INPUTS_READY, binding.VSYN_SUBMIT_INPUTS_READY | binding.VSYN_SUBMIT_PRE_KERNELS])
+def test_device_resident_back_to_back_submits_overlap_safely(flags):
+    """vsyn_submit_device with VSYN_SUBMIT_INPUTS_READY, back to back without a sync in between, each == oracle: with the preparation
+    kernel on the caller's stream (the default), and with the chained pre-kernels hidden beside the previous submit's synthesis kernel on
+    the internal stream, on double-buffered workspaces (+ VSYN_SUBMIT_PRE_KERNELS: the default of rounds 1-3)."""
     import torch
     spec = fixture_like_spec(2)
     S, ppk = 6, 40
@@ -302,7 +305,7 @@ def test_device_resident_back_to_back_submits_overlap_safely():
     torch.cuda.synchronize()
     for d, b in zip(keep, outs):
         gpu.submit_device(S * ppk, d["pk"].data_ptr(), S, d["seg"].data_ptr(), ppk, d["ys"].data_ptr(), d["res"].data_ptr(),
-                          d["pcm"].data_ptr(), b["plane_stride"], d["emit"].data_ptr(), None, binding.VSYN_SUBMIT_INPUTS_READY, stream)
+                          d["pcm"].data_ptr(), b["plane_stride"], d["emit"].data_ptr(), None, flags, stream)
     fl, bad = gpu.sync_status(stream)
     assert fl == 0, (fl, bad)
     for d, b in zip(keep, outs):
@@ -491,11 +494,12 @@ def test_absolute_gate_at_unit_peak(pattern):
 
 def test_submit_flags_may_alternate_between_submits():
     """vsyn_submit_device with a different preparation in every submit — the dependency-free preparation kernel on the caller's stream,
-    the chained pre-kernels on the internal stream (VSYN_SUBMIT_INPUTS_READY), the chained pre-kernels on the caller's stream
-    (VSYN_SUBMIT_PRE_KERNELS), the staged kernels — on continuing streams, with work queued on the caller's stream in front: consecutive
-    preparations chain through the tagged stream-state records whichever kernel writes them and whichever stream it runs on."""
-    FLAG_CYCLE = [0, binding.VSYN_SUBMIT_INPUTS_READY, binding.VSYN_SUBMIT_PRE_KERNELS, binding.VSYN_SUBMIT_INPUTS_READY,
-                  binding.VSYN_SUBMIT_STAGED, 0]
+    the chained pre-kernels hidden on the internal stream (VSYN_SUBMIT_INPUTS_READY | VSYN_SUBMIT_PRE_KERNELS), the chained pre-kernels
+    on the caller's stream (VSYN_SUBMIT_PRE_KERNELS), the staged kernels — on continuing streams, with work queued on the caller's stream
+    in front: consecutive preparations chain through the tagged stream-state records whichever kernel writes them and whichever stream it
+    runs on."""
+    FLAG_CYCLE = [0, HIDDEN_PRE, binding.VSYN_SUBMIT_PRE_KERNELS, HIDDEN_PRE, binding.VSYN_SUBMIT_INPUTS_READY,
+                  binding.VSYN_SUBMIT_STAGED, HIDDEN_PRE, 0]
     import torch
     spec = fixture_like_spec(2)
     S, ppk, parts = 4, 24, 6

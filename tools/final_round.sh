@@ -19,8 +19,8 @@ B="timeout -k 10 400 python bench.py"
   $B --no-cpu-baseline --pcm-s16 &&
   $B --no-cpu-baseline --feature-taps &&
   $B --no-cpu-baseline --steps 100 --feature-taps --blocksizes 128,1024 &&
-  VSYN_PREP_SERIAL=1 $B --steps 200 --warmup 10 --no-cpu-baseline &&
-  VSYN_PREP_SERIAL=1 $B --no-cpu-baseline --workload config4 &&
+  $B --steps 200 --warmup 10 --no-cpu-baseline --hidden-pre-kernels &&
+  $B --no-cpu-baseline --workload config4 --hidden-pre-kernels &&
   $B --no-cpu-baseline --steps 100 --workload config3 --blocksizes 128,1024 &&
   $B --no-cpu-baseline --steps 100 --workload config4 --blocksizes 128,1024 &&
   $B --no-cpu-baseline --steps 100 --workload config3 --blocksizes 512,512 &&
