@@ -789,14 +789,16 @@ static int submit_device_impl(vsyn_handle* h, uint32_t P, const vsyn_packet* d_p
     pc.fused_ok = fmask;
     pc.P = P;
     pc.epoch = epoch;
-    // a workgroup takes whole runs, as many as give about PREP_THREADS (packet, channel) rows
-    const uint32_t ppp = std::max<uint32_t>(1u, PREP_THREADS / C);
+    // a workgroup takes whole runs, as many as give about one (packet, channel) row per thread; a batch of short segments (thousands of
+    // streams with a few packets each) gets smaller workgroups — whole waves — instead of 256 threads with a handful of rows
+    const uint32_t nt = std::min<uint32_t>(PREP_THREADS, std::max<uint32_t>(64u, ((max_seg_packets * C + 63u) / 64u) * 64u));
+    const uint32_t ppp = std::max<uint32_t>(1u, nt / C);
     pc.chunk_runs = std::max<uint32_t>(1u, ppp / R);
     pc.chunks_per_seg = (runs_per_seg + pc.chunk_runs - 1u) / pc.chunk_runs;
     // a layout workgroup and a floor workgroup per (segment, chunk), dealt in alternating groups of eight (vsyn_prep.h)
     const uint64_t wgs = (((uint64_t)S * pc.chunks_per_seg + 7u) / 8u) * 16u;
     if (wgs > 0x7FFFFFF0ull) return fail(err, VSYN_ERR_INVALID, "too many runs");
-    vsyn_prep_kernel<<<(uint32_t)wgs, PREP_THREADS, h->prep_lds_bytes, ps>>>(pc);
+    vsyn_prep_kernel<<<(uint32_t)wgs, nt, h->prep_lds_bytes, ps>>>(pc);
   }
   h->last_ran_layout = !prep_kernel;
   h->last_prep_on_main = ps == s;

@@ -100,7 +100,8 @@ __device__ __forceinline__ void prep_unwrap_rows(const PrepCtx& A, const bool ac
   typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
   typedef const __attribute__((address_space(4))) u32x16* const_grp;
   typedef const __attribute__((address_space(4))) uint32_t* kptr;
-  prep_lds_u32* const col = rowbuf + threadIdx.x;  // post i of this thread's row at col[i * PREP_THREADS]
+  const uint32_t NT = blockDim.x;
+  prep_lds_u32* const col = rowbuf + threadIdx.x;  // post i of this thread's row at col[i * NT]
   uint64_t todo = __ballot(act);
   while (todo) {
     const uint32_t f = __builtin_amdgcn_readlane(fl_id, (uint32_t)__builtin_ctzll(todo));
@@ -207,10 +208,10 @@ __device__ __forceinline__ void prep_unwrap_rows(const PrepCtx& A, const bool ac
       const uint2* in8 = (const uint2*)(A.ys + gid * stride);
       for (uint32_t j = 0; j * 4 < posts; ++j) {
         const uint2 w = in8[j];
-        col[(4 * j + 0) * PREP_THREADS] = w.x & 0xFFFFu;
-        col[(4 * j + 1) * PREP_THREADS] = w.x >> 16;
-        col[(4 * j + 2) * PREP_THREADS] = w.y & 0xFFFFu;
-        col[(4 * j + 3) * PREP_THREADS] = w.y >> 16;
+        col[(4 * j + 0) * NT] = w.x & 0xFFFFu;
+        col[(4 * j + 1) * NT] = w.x >> 16;
+        col[(4 * j + 2) * NT] = w.y & 0xFFFFu;
+        col[(4 * j + 3) * NT] = w.y >> 16;
       }
     }
     uint64_t flags_lo = 3;
@@ -223,9 +224,9 @@ __device__ __forceinline__ void prep_unwrap_rows(const PrepCtx& A, const bool ac
       uint32_t val[4], ylo[4], yhi[4], fn[4], prod[4], off[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        val[e] = col[kq[4 * e + 3] * PREP_THREADS];
-        ylo[e] = col[(kq[4 * e] & 0xFFFFu) * PREP_THREADS];
-        yhi[e] = col[(kq[4 * e] >> 16) * PREP_THREADS];
+        val[e] = col[kq[4 * e + 3] * NT];
+        ylo[e] = col[(kq[4 * e] & 0xFFFFu) * NT];
+        yhi[e] = col[(kq[4 * e] >> 16) * NT];
       }
       bool any_big = false;
 #pragma unroll
@@ -265,7 +266,7 @@ __device__ __forceinline__ void prep_unwrap_rows(const PrepCtx& A, const bool ac
         bad = bad || !ok;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) col[kq[4 * e + 3] * PREP_THREADS] = bad ? 0u : fn[e];  // (a row with an out-of-range prediction is dropped: keep the chain tame)
+      for (int e = 0; e < 4; ++e) col[kq[4 * e + 3] * NT] = bad ? 0u : fn[e];  // (a row with an out-of-range prediction is dropped: keep the chain tame)
     }
     uint2* out8 = (uint2*)(A.fy + gid * stride);
     if (bad) raise_status(A.status, VSYN_ST_FLOOR_RANGE, p);
@@ -274,7 +275,7 @@ __device__ __forceinline__ void prep_unwrap_rows(const PrepCtx& A, const bool ac
 #pragma unroll
       for (uint32_t e = 0; e < 4; ++e) {
         const uint32_t i = 4 * j + e;
-        const uint32_t fv = i < posts ? col[i * PREP_THREADS] : 0u;
+        const uint32_t fv = i < posts ? col[i * NT] : 0u;
         uint32_t v = fv * mult;  // hpp:573,578
         if (v > 0x7FFFu || fv > 0x7FFFu) v = 0x7FFFu;  // wrapped / absurd amplitude: renders >= 256 -> FLOOR_VALUE later
         const uint32_t fl = i < 64 ? (uint32_t)((flags_lo >> i) & 1ull) : (i == 64 ? flag_64 : 0u);
@@ -298,8 +299,10 @@ __device__ __forceinline__ void prep_block_scan(AbsScan& inc, uint64_t& rinc, Ab
   __syncthreads();
   AbsScan pre = {0, 0}, tot = {0, 0};
   uint64_t rpre = 0, rtot = 0;
+  const uint32_t nw = blockDim.x >> 6;
 #pragma unroll
   for (uint32_t w = 0; w < PREP_WAVES; ++w) {
+    if (w >= nw) break;
     const AbsScan a = s_abs[w];
     const uint64_t r = s_res[w];
     if (w < wv) {
@@ -328,6 +331,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   const uint8_t* __restrict__ cb = A.cb;
   const ConstHeader* H = hdr_of(cb);
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t NT = blockDim.x;  // 64 ... PREP_THREADS: the host sizes the workgroup to the rows a (segment, chunk) can have
   const uint32_t C = H->channels;
   // Two kinds of workgroup per (segment, chunk), dealt alternately so that both start at once: even blockIdx = the LAYOUT of the chunk's
   // packets (scan, PktInfo, run classes, stream state), odd = FLOOR-1 STEP 1 of their rows ("even / odd" in the sense spelled out below). The rows need nothing the scan produces —
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   uint8_t* const cls_row = A.run_cls + (size_t)g * A.runs_per_seg;
   if (sg.stream >= H->max_streams || (uint64_t)sg.first_packet + sg.num_packets > A.P || (sg.residue_off & 3)) {
     if (role) return;
-    for (uint32_t r = run0 + t; r < run1; r += PREP_THREADS) cls_row[r] = 0xFFu;
+    for (uint32_t r = run0 + t; r < run1; r += NT) cls_row[r] = 0xFFu;
     if (ch == 0u && t == 0u) {
       raise_status(A.status, VSYN_ST_BAD_SEGMENT, sg.first_packet < A.P ? sg.first_packet : 0);
       A.sinfo[g] = SegInfo{0, 0, 0, 0};
@@ -390,7 +394,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
     const MapConst* const maps = (const MapConst*)(cb + H->off_map);
     const uint32_t chan_mask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
     const uint32_t num_modes = H->num_modes;
-    const uint32_t ppp = PREP_THREADS / C;
+    const uint32_t ppp = NT / C;
     for (uint32_t base = cs; base < ce; base += ppp) {
       const uint32_t pe = min(ce, base + ppp);
       const uint32_t rp = t / C, c = t - rp * C;
@@ -439,7 +443,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   si.parity_in = reset ? 0u : st0.parity;
   si.total_emit = 0;
   if (cs >= num) {  // the chunk lies beyond the segment's end (an empty segment: chunk 0 keeps its records in order)
-    for (uint32_t r = run0 + t; r < run1; r += PREP_THREADS) cls_row[r] = 0xFFu;
+    for (uint32_t r = run0 + t; r < run1; r += NT) cls_row[r] = 0xFFu;
     if (num == 0u && ch == 0u && t == 0u) {
       A.sinfo[g] = si;
       if (reset) state_write(A.state, sg.stream, st_slot, StreamState{0, 0, 0, 0, 0}, A.epoch);
@@ -455,7 +459,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   uint32_t prev_n_in = carry_n;
   bool halo_long = !carry_n;  // the block in front of the chunk is a valid long one (or there is none at all)
   if (cs > 0u) {
-    const uint32_t per = (cs + PREP_THREADS - 1u) / PREP_THREADS;
+    const uint32_t per = (cs + NT - 1u) / NT;
     const uint32_t b = min(cs, t * per), e = min(cs, b + per);
     AbsScan agg = {0, 0};
     uint64_t res = 0;
@@ -493,8 +497,8 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   const uint32_t chan_mask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
   // packets per pass: as many whole packets as give at most PREP_THREADS rows (a stream of more than PREP_THREADS channels — there is
   // none: VSYN_MAX_CHANNELS is 32 — would need rows of one packet spread over passes)
-  const uint32_t ppp = PREP_THREADS / C;
-  for (uint32_t w = t; w < (ce - cs + 1u + 31u) / 32u; w += PREP_THREADS) s_longbits[w] = 0u;
+  const uint32_t ppp = NT / C;
+  for (uint32_t w = t; w < (ce - cs + 1u + 31u) / 32u; w += NT) s_longbits[w] = 0u;
   __syncthreads();
   if (t == 0u && halo_long) s_longbits[0] = 1u;
   for (uint32_t base = cs; base < ce; base += ppp) {
@@ -615,7 +619,7 @@ __global__ void __launch_bounds__(PREP_THREADS) vsyn_prep_kernel(const PrepCtx A
   __syncthreads();
   {
     const uint32_t nruns_seg = (num + R - 1u) / R;
-    for (uint32_t r = run0 + t; r < run1; r += PREP_THREADS) {
+    for (uint32_t r = run0 + t; r < run1; r += NT) {
       uint32_t cls = 0xFFu;  // no such run
       if (r < nruns_seg) {
         const uint32_t first = r * R - cs, end = min(num, (r + 1u) * R) - cs;  // bits first (the halo) .. end (the run's last packet)
