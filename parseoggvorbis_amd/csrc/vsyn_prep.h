@@ -5,23 +5,25 @@
 // the previous submit's synthesis kernel on a second queue they cost an event record and a cross-queue wait per submit (12-19 us
 // between two synthesis kernels; tools/stream_sync_bench.hip: no cheaper ordering primitive, hipExtAnyOrderLaunch is ignored on this
 // part) and their waves compete with an exact-fit synthesis grid for wave slots (+6 us on the synthesis kernel). This kernel is short
-// enough to simply run IN FRONT of the synthesis kernel on the caller's stream: a submit is two launches on one queue, no second
-// queue, no events. Who gets it (vorbis_synth_hip.hip, submit_device_impl): every submit without VSYN_SUBMIT_INPUTS_READY, and with it
-// the submits of the size-generic kernel <1>, where it measured 2-4 % faster per step than the hidden pre-kernels; the 256/2048 kernel
-// keeps the hidden pre-kernels for device-resident pipelines (a tie on config 3, 3-4 % better on config 4).
+// enough (~17 us for 65 536 stereo packets) to simply run IN FRONT of the synthesis kernel on the caller's stream: a submit is two
+// launches on one queue, no second queue, no events. Who gets it (vorbis_synth_hip.hip, submit_device_impl): every submit whose runs all
+// go to fused kernels, whose segments have at most PREP_MAX_SEG_PACKETS packets and which carries no residue-VQ stage — with or without
+// VSYN_SUBMIT_INPUTS_READY (profiles/r03_experiments/batch_preparation_ab.txt: 1-4 % faster per step than the hidden pre-kernels).
 //
-// One wave per (segment, run [qa, qb) of the synthesis kernels, channel c); lane j <-> packet qa + j:
-//   1. the scan's running values in front of the run — absolute position (granule-aware, hpp:1028-1044), residue offset, block size —
-//      by a reduction over the segment's earlier descriptors (each lane a contiguous piece, one wave scan): every wave does that for
-//      itself instead of waiting for a predecessor, which is what makes the kernel dependency-free (a segment has at most
-//      PREP_MAX_SEG_PACKETS packets here: a lane's piece is at most 64 descriptors; longer segments keep the layout kernel's
-//      chunked scan);
-//   2. PktInfo of the run's packets by a wave scan (pkt_step, shared with the layout kernel), emit_len, the run's class from a ballot
-//      over its block flags (channel 0's wave writes them);
-//   3. floor-1 step 1 (hpp:521-559), one lane per (packet, channel) row (prep_unwrap_rows): floors of up to 32 posts as a branch-free
-//      chain over a register array, longer ones with the row's posts in LDS, four independent posts at a time;
-//   4. the wave of a segment's last run (channel 0) leaves the stream state for the next submit (tagged records, vsyn_device.h) and
-//      the segment's SegInfo.
+// Two kinds of workgroup per (segment, chunk of whole runs, about one (packet, channel) row per thread), running side by side:
+//   LAYOUT (threads <-> packets)
+//   1. the scan's running values in front of the chunk — absolute position (granule-aware, hpp:1028-1044), residue offset, block size —
+//      by a reduction over the segment's EARLIER descriptors (each thread a contiguous piece, one block scan): every workgroup does
+//      that for itself instead of waiting for a predecessor, which is what makes the kernel dependency-free (a segment has at most
+//      PREP_MAX_SEG_PACKETS packets here; longer segments keep the layout kernel's chunked scan);
+//   2. PktInfo of the chunk's packets by a block scan (pkt_step_core, shared with the layout kernel), emit_len, the class of each run
+//      from a bitmap of its packets' block flags;
+//   3. the thread of a segment's last packet leaves the stream state for the next submit (tagged records, vsyn_device.h) and the
+//      segment's SegInfo.
+//   FLOOR (threads <-> (packet, channel) rows)
+//   4. floor-1 step 1 (hpp:521-559, prep_unwrap_rows): which floor, and whether the channel carries a curve, follow from the packet's
+//      own descriptor — nothing the scan produces is needed; floors of up to 32 posts as a branch-free chain over a register array,
+//      longer ones with the row's posts in LDS, four independent posts at a time.
 #pragma once
 #include <hip/hip_runtime.h>
 
