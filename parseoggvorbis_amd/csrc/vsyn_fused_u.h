@@ -1,6 +1,8 @@
-// vsyn_fused_u.h — the size-generic fused synthesis kernel ("U"): every block-size pair 64..2048 (the reference runs every
-// size through the same code, hpp:1294-1298, mdct.cpp:353-373), any mix of short and long blocks, carry-ins, <= 2 channels with
-// at most one coupling step, <= 64 floor posts (this kernel: up to the spec's 65). One wavefront per (segment, run, channel) as in vsyn_fused.h; what is new:
+// vsyn_fused_u.h — the size-generic fused synthesis kernel ("U"): every block-size pair 64..8192 with blocksize0 <= 2048 or equal to
+// blocksize1 (the reference runs every size through the same code, hpp:1294-1298, mdct.cpp:353-373; blocks above 2048 as 2 / 4 register
+// sets, UBig), any mix of short and long blocks, carry-ins, up to 16 coupled channels with any list of coupling steps (ROLE 3: replayed in
+// place by the channel waves of a run, which share a workgroup) or any number of uncoupled ones, floors of up to the spec's 65 posts. One
+// wavefront per (segment, run, channel) as in vsyn_fused.h; what is new:
 //
 //   * a wave always works on 512 complex points = 8 per lane. A block of n samples has Np = n/4 points, so a PASS takes
 //     J = 512/Np consecutive packets of the same size and mapping at once (n = 256: 8 packets; n = 1024: 2; n = 2048: 1; at most 8):
@@ -12,9 +14,10 @@
 //     lane-major tables (ULdsSize) and a few wave-uniform scalars: the device code is one instance.
 //   * the overlap term of packet j comes from packet j-1 of the same pass (G lanes below, one ds_bpermute per register), from the
 //     previous pass (registers), or — when the block size changes — through the wave's carry image, exactly as in vsyn_fused.h.
-//   * the floor curve is evaluated in bin order (4 consecutive bins per lane, tables per packet in turn) into the idle exchange
-//     image and read back in element order; everything else follows vsyn_fused.h (same roundings: coupling and floor product
-//     bit-exact, window product and overlap sum rounded separately, hpp:1008-1017).
+//   * the floor: one table of per-interval line records per packet of the pass, side by side in the idle exchange image; every element
+//     reads the records of its two bins from the table of its own packet (round 2 rendered each packet in bin order and staged the
+//     factors through LDS); everything else follows vsyn_fused.h (same roundings: coupling and floor product bit-exact, window
+//     product and overlap sum rounded separately, hpp:1008-1017).
 #pragma once
 #include <hip/hip_runtime.h>
 
